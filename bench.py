@@ -1,0 +1,201 @@
+"""Benchmark of the projective-ICP pose loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one complete pose loop: 20 LM iterations (stop test disabled) over a synthetic
+correspondence set that is already resident in HBM.  N = 1 runs the single-GPU configuration
+(2^20 correspondences); N > 1 shards 2^26 correspondences over the N GPUs with two small
+all-reduces per iteration.  Rank 0 prints one JSON line.
+
+metric = correspondence-iterations per second, whole job.
+roofline = the stage-2 scan (linearise + H/b reduction): algorithmic bytes (40 B per
+correspondence per launch) over its mean launch duration, against the 8 TB/s HBM3E peak.
+cpu_baseline = the numpy restatement (oracle/) on the host, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E nominal peak
+BYTES_PER_CORR_PER_SCAN = 40   # u, v, x, y, z as float64
+ITERATIONS = 20
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--corr", type=int, default=0, help="total correspondences (default 2^20 at 1 GPU, 2^26 sharded)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iterations", type=int, default=10)
+    return ap.parse_args()
+
+
+def device_problem(ctx, M, lo, hi, seed=0, chunk=1 << 22):
+    """Correspondences [lo, hi) of the seeded M-point problem as five device arrays, generated in
+    chunks so the host never holds more than one chunk.  Chunk c uses seed (seed, c), so any
+    sharding of the same M yields the same global data."""
+    from tests.synthetic import make_problem
+    from importlib import import_module
+    n = hi - lo
+    stride = import_module("monocular-visual-odometry_amd")._lib._pad32(n)
+    planes = ctx.zeros((5, stride))
+    c0 = lo // chunk
+    c1 = (hi + chunk - 1) // chunk
+    for c in range(c0, c1):
+        beg, end = c * chunk, min((c + 1) * chunk, M)
+        uv, pw, _ = make_problem(end - beg, seed=[seed, c])
+        a, b = max(lo, beg), min(hi, end)
+        if a >= b:
+            continue
+        block = np.concatenate([uv[a - beg:b - beg].T, pw[a - beg:b - beg].T], axis=0)
+        planes[:, a - lo:b - lo] = ctx.to_device(np.ascontiguousarray(block))
+    return [planes[k][:n] for k in range(5)]
+
+
+def time_stage2(ctx, pkg, corr, cam, sched, reps=40):
+    """Mean duration of one stage-2 launch, from HIP events recorded on the launch stream around
+    each launch (torch's current stream is the stream the library launches on)."""
+    import torch
+    L = pkg._lib
+    lib, h = ctx.lib, ctx.handle
+    M = int(corr[0].numel())
+    state = ctx.empty(L.STATE_DOUBLES)
+    pose = np.ascontiguousarray(np.eye(4).reshape(16))
+    ptrs = [ctx.ptr(c) for c in corr]
+    L.check(lib.picp_state_init(h, ctx.ptr(state), pose.ctypes.data_as(C.c_void_p), C.byref(sched)), "state_init")
+    L.check(lib.picp_stage1(h, *ptrs, M, ctx.ptr(state), C.byref(cam)), "stage1")
+    for _ in range(3):
+        L.check(lib.picp_stage2(h, *ptrs, M, ctx.ptr(state), C.byref(cam), None), "stage2")
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    for k in range(reps):
+        starts[k].record()
+        L.check(lib.picp_stage2(h, *ptrs, M, ctx.ptr(state), C.byref(cam), None), "stage2")
+        ends[k].record()
+    torch.cuda.synchronize()
+    ms = np.array([s.elapsed_time(e) for s, e in zip(starts, ends)])
+    return float(ms.mean()), float(ms.min())
+
+
+def cpu_baseline(M, iterations):
+    """The numpy restatement of the loop on the host: one process, numpy element-wise kernels
+    (single core), on the first `iterations` iterations of the same M-correspondence problem."""
+    from oracle import picp_oracle as po
+    from tests.synthetic import make_problem
+    M = min(M, 1 << 20)
+    uv, pw, _ = make_problem(M, seed=[0, 0])
+    params = po.IcpParams(num_iterations=iterations, disable_stop=True)
+    t0 = time.perf_counter()
+    po.projective_icp(uv, pw, np.eye(4), params)
+    dt = time.perf_counter() - t0
+    return {"value": M * iterations / dt, "unit": "correspondence-iterations/s", "cores": 1, "kind": "port",
+            "sample": f"numpy float64 restatement, {M} correspondences x {iterations} LM iterations, "
+                      f"{dt:.1f} s on 1 of {os.cpu_count()} host CPUs"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from tests.synthetic import true_pose
+    pkg = importlib.import_module("monocular-visual-odometry_amd")
+    L = pkg._lib
+    ctx = pkg.get_context(local_rank)
+
+    M = args.corr or ((1 << 20) if world == 1 else (1 << 26))
+    lo, hi = pkg.sharded.shard_bounds(M, rank, world)
+    corr = device_problem(ctx, M, lo, hi)
+    cam = L.camera_struct([[180, 0, 320], [0, 180, 240], [0, 0, 1]], 640, 480)
+    sched = L.schedule_struct(ITERATIONS, 10, 1000, 10, 2000, 64, 1, 64, disable_stop=True)
+    pose0 = np.eye(4)
+
+    def step():
+        if world == 1:
+            res, _ = ctx.run(corr, pose0, cam, sched, want_history=False)
+        else:
+            stages = pkg.sharded.HipStages(ctx, corr, pose0, cam, sched, want_history=False)
+            res, _ = pkg.sharded.run_sharded(stages, ITERATIONS, disable_stop=True)
+        return res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert res.num_iterations == ITERATIONS, res.num_iterations
+
+    s2_mean_ms, s2_min_ms = time_stage2(ctx, pkg, corr, cam, sched)
+    if rank == 0:
+        n_local = hi - lo
+        achieved = BYTES_PER_CORR_PER_SCAN * n_local / (s2_mean_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ICP correspondence-iterations/sec",
+            "value": M * ITERATIONS * args.steps / dt,
+            "unit": "correspondence-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("synthetic single-pose projective ICP, 2^20 correspondences, 20 LM iterations"
+                                    if world == 1 and M == (1 << 20) else
+                                    f"synthetic single-pose projective ICP, {M} correspondences sharded over "
+                                    f"{world} GPU(s), 20 LM iterations, 2 all-reduces per iteration"),
+                       "correspondences": M, "lm_iterations": ITERATIONS,
+                       "final_pose_error": float(np.max(np.abs(np.array(list(res.T)).reshape(4, 4) - true_pose())))},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "stage2_kernel (linearise + H/b reduction)",
+                         "bytes_per_launch": BYTES_PER_CORR_PER_SCAN * n_local,
+                         "mean_launch_ms": s2_mean_ms, "min_launch_ms": s2_min_ms,
+                         "loop_bytes_per_corr_iteration": 2 * BYTES_PER_CORR_PER_SCAN,
+                         "loop_achieved_GBs": 2 * BYTES_PER_CORR_PER_SCAN * n_local * ITERATIONS * args.steps / dt / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(M, args.cpu_iterations)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+/*
+ * picp_hip.h -- C ABI of libpicp_hip.so: the projective-ICP pose loop and the appearance
+ * association of ValerioSpagnoli/Monocular-Visual-Odometry as hand-written HIP kernels for
+ * gfx950 (MI355X).
+ *
+ * The reference is pure Python and has no FFI; its operator interface for this path is two
+ * Python callables (src/ProjectiveICP.py:8-381, src/data_association.py:3-57).  Every entry
+ * point below names the reference lines whose behaviour it reproduces.  The package's Python
+ * classes of the same names bind these symbols through ctypes.
+ *
+ * Conventions
+ *  - every function returns PICP_OK (0) or a negative PICP_ERR_* code and never throws;
+ *    picp_last_error() returns a human-readable message for the calling thread's last failure;
+ *  - "device" pointers are HIP device addresses (e.g. torch.Tensor.data_ptr()); the caller owns
+ *    every buffer it passes; "host" pointers are ordinary process memory;
+ *  - all floating point data is IEEE float64; matrices are row-major; poses are 4x4 with last
+ *    row (0,0,0,1), as every pose the reference builds (src/geometry_utils.py:38-57);
+ *  - one picp_ctx per device and stream; a ctx is not thread-safe; work is enqueued on the ctx's
+ *    stream and, unless a function says it synchronises, returns before the GPU has finished;
+ *  - correspondences are struct-of-arrays: u[M], v[M] (measured pixel), x[M], y[M], z[M] (map
+ *    point in the frame poses are expressed in), so that consecutive lanes read consecutive
+ *    8-byte words.
+ */
+#ifndef PICP_HIP_H
+#define PICP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PICP_VERSION 100
+
+#define PICP_OK 0
+#define PICP_ERR_INVALID (-1)   /* bad argument (null pointer, negative size, pose last row != 0,0,0,1) */
+#define PICP_ERR_HIP (-2)       /* a HIP runtime call failed; see picp_last_error() */
+#define PICP_ERR_CAPACITY (-3)  /* an output buffer is too small; the needed size is reported */
+#define PICP_ERR_NO_DEVICE (-4) /* no usable gfx950 device */
+
+/* Doubles per row of the per-iteration history and of the device state block. */
+#define PICP_HIST_STRIDE 80
+#define PICP_STATE_DOUBLES 96
+/* Doubles in the stage-1 / stage-2 reduction records (the all-reduce payloads when sharded). */
+#define PICP_S1_DOUBLES 4
+#define PICP_S2_DOUBLES 64
+
+/* History row layout (doubles).  Rows 0..19 are the reference's five per-iteration lists
+ * (src/ProjectiveICP.py:173, :233-237); the rest is recorded for parity checks. */
+#define PICP_H_T 0            /* [16] pose w_T_c after this iteration's step            (:233) */
+#define PICP_H_ERROR 16       /* mean chi of the final inlier set, +inf if none          (:234) */
+#define PICP_H_NUM_INLIERS 17 /*                                                         (:235) */
+#define PICP_H_KERNEL_THR 18  /* kernel threshold AFTER this iteration's update          (:236) */
+#define PICP_H_DAMPING 19     /* damping AFTER this iteration's update                   (:237) */
+#define PICP_H_N_INSIDE 20    /* pairs whose map point projects inside the image (len(reference_image_points), :200) */
+#define PICP_H_DONE 21        /* computation_done                                        (:263, :273) */
+#define PICP_H_N_STAGE1 22    /* survivors of chi <= kernel_threshold                    (:294) */
+#define PICP_H_N_STAGE2 23    /* survivors of chi < mean                                 (:302) */
+#define PICP_H_USED_STAGE2 24 /* 1 when the stage-2 set replaced the stage-1 set         (:307) */
+#define PICP_H_MEAN_STAGE1 25 /* mean chi of the stage-1 set                             (:301) */
+#define PICP_H_DX 26          /* [6] solution of the damped system                       (:270) */
+#define PICP_H_B 32           /* [6] b before the solve                                  (:317) */
+#define PICP_H_H 38           /* [36] H before damping, row-major                        (:316) */
+
+/* Camera model: K and the image size used by Camera.project_point (src/Camera.py:82-121).
+ * The reference parses K with int() (src/Camera.py:23); pass the values as doubles. */
+typedef struct picp_camera {
+    double K[9];
+    double width;  /* u must satisfy 0 <= u < width   (src/Camera.py:117) */
+    double height; /* v must satisfy 0 <= v < height  (src/Camera.py:118) */
+} picp_camera;
+
+/* Loop parameters = ProjectiveICP constructor arguments (src/ProjectiveICP.py:9-18). */
+typedef struct picp_schedule {
+    int32_t num_iterations;
+    int32_t min_inliers;
+    double kernel_threshold;
+    double min_kernel_threshold;
+    double max_kernel_threshold;
+    double damping; /* "dumping_factor" in the reference */
+    double min_damping;
+    double max_damping;
+    int32_t disable_stop; /* 1: ignore the stop test (:228) and always run num_iterations (benchmarks) */
+    int32_t reserved;
+} picp_schedule;
+
+/* Result of a whole loop (src/ProjectiveICP.py:249-257). */
+typedef struct picp_result {
+    double T[16];           /* returned pose: best iteration's pose, or the start pose if invalid */
+    int32_t valid;          /* 0 when the best iteration's error is > 5 (:249) */
+    int32_t num_iterations; /* iterations actually run */
+    int32_t best_index;     /* first argmin of the error list (:249, :254) */
+    int32_t reserved;
+    double best_error;
+} picp_result;
+
+typedef struct picp_ctx picp_ctx;
+
+int picp_version(void);
+const char* picp_last_error(void);
+
+/* stream: a hipStream_t (NULL = the default stream).  Allocates the ctx's reduction workspace. */
+int picp_create(picp_ctx** ctx, int device, void* stream);
+int picp_destroy(picp_ctx* ctx);
+int picp_set_stream(picp_ctx* ctx, void* stream);
+int picp_synchronize(picp_ctx* ctx);
+
+/* ---- the LM loop, one call (src/ProjectiveICP.py:154-257 on pre-associated pairs) ----------
+ * Runs up to sched->num_iterations iterations of: in-image filter of every pair under the
+ * current pose (the pose-dependent part of the association call at :182, src/data_association.py:44-46),
+ * linearise (:276-353), damped solve + pose update (:260-273), schedules (:200-228).
+ * hist: device, [hist_rows][PICP_HIST_STRIDE], hist_rows >= num_iterations.
+ * state: device, PICP_STATE_DOUBLES doubles of scratch owned by the caller.
+ * Synchronises the stream before returning; result is host memory. */
+int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
+             int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched,
+             double* state, double* hist, int32_t hist_rows, picp_result* result);
+
+/* Same loop for B independent problems in one launch, one workgroup per problem, the whole loop
+ * inside the kernel.  Problem p owns correspondences [offsets[p], offsets[p+1]).
+ * offsets: device int64[B+1]; poses0: device [B][16]; results: device picp_result[B];
+ * hist: device [B][hist_rows][PICP_HIST_STRIDE] or NULL (then only results are produced).
+ * Does not synchronise. */
+int picp_run_batched(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                     const double* z, const int64_t* offsets, int32_t B, const double* poses0,
+                     const picp_camera* cam, const picp_schedule* sched, picp_result* results, double* hist,
+                     int32_t hist_rows);
+
+/* ---- the loop's stages, for callers that interleave their own exchange (sharded runs) ------
+ * picp_state_init   = loop entry (:157-171): pose, inverse pose, thresholds, counters.
+ * picp_stage1       = first scan: per pair in-image test and chi; sums {sum chi, count} of the
+ *                     pairs with chi <= kernel_threshold (:289-297) and the in-image count.
+ * picp_stage2       = second scan: mean filter (:301-310) and the H, b sums (:313-317) of both
+ *                     candidate inlier sets.
+ * picp_solve        = damped solve, pose update, schedules, history row (:269-271, :200-238).
+ * Each stage leaves per-workgroup partial sums in the ctx.  picp_stage1_reduce /
+ * picp_stage2_reduce fold them into one record in caller memory (device, PICP_S1_DOUBLES /
+ * PICP_S2_DOUBLES doubles) that the caller may all-reduce(sum) across shards and hand to the
+ * next stage through s1 / s2.  Passing NULL for s1 / s2 makes the next stage fold the ctx's
+ * partial sums itself (single-GPU path, no extra launch).  None of these synchronise; every
+ * stage is a no-op once the state's stop flag is set. */
+int picp_state_init(picp_ctx* ctx, double* state, const double* w_T_c0_host, const picp_schedule* sched);
+int picp_stage1(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                const double* z, int64_t M, const double* state, const picp_camera* cam);
+int picp_stage1_reduce(picp_ctx* ctx, double* s1);
+int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                const double* z, int64_t M, const double* state, const picp_camera* cam, const double* s1);
+int picp_stage2_reduce(picp_ctx* ctx, double* s2);
+int picp_solve(picp_ctx* ctx, double* state, const picp_schedule* sched, const double* s1, const double* s2,
+               double* hist, int32_t hist_rows);
+/* Reads the history back (synchronises) and applies the best-iteration rule (:249-257). */
+int picp_finish(picp_ctx* ctx, const double* state, const double* hist, int32_t hist_rows,
+                const double* w_T_c0_host, picp_result* result);
+
+/* ---- single calls mirroring the reference's private methods, for tests ---------------------
+ * picp_linearize = __linearize (src/ProjectiveICP.py:276-323).  Synchronises.
+ * Host outputs: H[36], b[6], num_inliers, error, n_inside. */
+int picp_linearize(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                   const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
+                   double kernel_threshold, int32_t min_inliers, double* H, double* b, int64_t* num_inliers,
+                   double* error, int64_t* n_inside);
+
+/* ---- appearance association (src/data_association.py:3-57) ---------------------------------
+ * All pairs (i, j) whose D-component descriptors are equal component by component under float
+ * equality (-0.0 == 0.0, NaN never equal: Python list equality at :31), in i-major, j-minor
+ * order (:29-30).  app1: device [N1][D], app2: device [N2][D]; idx1/idx2: device int64[capacity].
+ * *count (host) receives the number of pairs; if it exceeds capacity nothing past capacity is
+ * written and PICP_ERR_CAPACITY is returned.  Synchronises. */
+int picp_associate(picp_ctx* ctx, const double* app1, int64_t N1, const double* app2, int64_t N2, int32_t D,
+                   int64_t* idx1, int64_t* idx2, int64_t capacity, int64_t* count);
+
+/* Camera.project_point for N points (src/Camera.py:82-121): inside[N] (uint8, device) and the
+ * projected pixel uv_u[N], uv_v[N] (device; written for every point, meaningful where inside).
+ * c_T_w_host: the camera state matrix (src/Camera.py:76).  Does not synchronise. */
+int picp_project(picp_ctx* ctx, const double* x, const double* y, const double* z, int64_t N,
+                 const double* c_T_w_host, const picp_camera* cam, uint8_t* inside, double* uv_u, double* uv_v);
+
+/* Builds the SoA correspondence arrays from pair indices: u,v from pos1[N1][2] rows idx1[k],
+ * x,y,z from pos2[N2][3] rows idx2[k] (the np.array(matches[...]) step at src/ProjectiveICP.py:183-184).
+ * Does not synchronise. */
+int picp_gather_pairs(picp_ctx* ctx, const int64_t* idx1, const int64_t* idx2, int64_t n, const double* pos1,
+                      const double* pos2, double* u, double* v, double* x, double* y, double* z);
+
+/* 4x4 inverse as the loop computes it for camera.set_c_T_w (:232), host in / host out, runs on
+ * the GPU so tests can pin the device routine.  Synchronises. */
+int picp_invert_pose(picp_ctx* ctx, const double* T_host, double* Tinv_host);
+/* v2T (src/geometry_utils.py:38-45) evaluated by the device routine.  Synchronises. */
+int picp_v2T(picp_ctx* ctx, const double* v6_host, double* T_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PICP_HIP_H */

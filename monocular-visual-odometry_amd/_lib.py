@@ -1,0 +1,328 @@
+"""ctypes binding of libpicp_hip.so (C ABI declared in include/picp_hip.h).
+
+There is no CPU fallback: importing this module without the built library, or creating a
+context without a gfx950 GPU, raises.  PyTorch is used only to own device memory and to name
+the HIP stream work is enqueued on.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpicp_hip.so")
+
+HIST_STRIDE = 80
+STATE_DOUBLES = 96
+S1_DOUBLES = 4
+S2_DOUBLES = 64
+
+# history row layout (include/picp_hip.h)
+H_T, H_ERROR, H_NUM_INLIERS, H_KERNEL_THR, H_DAMPING = 0, 16, 17, 18, 19
+H_N_INSIDE, H_DONE, H_N_STAGE1, H_N_STAGE2, H_USED_STAGE2, H_MEAN_STAGE1 = 20, 21, 22, 23, 24, 25
+H_DX, H_B, H_H = 26, 32, 38
+# state block layout (csrc/picp_device.h)
+ST_W_T_C, ST_C_T_W, ST_THR, ST_LAMBDA, ST_IT, ST_STOP = 0, 16, 32, 33, 39, 40
+
+PICP_OK = 0
+PICP_ERR_CAPACITY = -3
+
+
+class PicpError(RuntimeError):
+    pass
+
+
+class CameraStruct(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("width", C.c_double), ("height", C.c_double)]
+
+
+class ScheduleStruct(C.Structure):
+    _fields_ = [("num_iterations", C.c_int32), ("min_inliers", C.c_int32),
+                ("kernel_threshold", C.c_double), ("min_kernel_threshold", C.c_double),
+                ("max_kernel_threshold", C.c_double), ("damping", C.c_double),
+                ("min_damping", C.c_double), ("max_damping", C.c_double),
+                ("disable_stop", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ResultStruct(C.Structure):
+    _fields_ = [("T", C.c_double * 16), ("valid", C.c_int32), ("num_iterations", C.c_int32),
+                ("best_index", C.c_int32), ("reserved", C.c_int32), ("best_error", C.c_double)]
+
+
+RESULT_DOUBLES = C.sizeof(ResultStruct) // 8
+assert C.sizeof(ResultStruct) == 8 * 19
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "picp_version": (C.c_int, []),
+    "picp_last_error": (C.c_char_p, []),
+    "picp_create": (C.c_int, [C.POINTER(_P), C.c_int, _P]),
+    "picp_destroy": (C.c_int, [_P]),
+    "picp_set_stream": (C.c_int, [_P, _P]),
+    "picp_synchronize": (C.c_int, [_P]),
+    "picp_run": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
+                           C.POINTER(ScheduleStruct), _P, _P, C.c_int32, C.POINTER(ResultStruct)]),
+    "picp_run_batched": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(CameraStruct),
+                                   C.POINTER(ScheduleStruct), _P, _P, C.c_int32]),
+    "picp_state_init": (C.c_int, [_P, _P, _P, C.POINTER(ScheduleStruct)]),
+    "picp_stage1": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct)]),
+    "picp_stage1_reduce": (C.c_int, [_P, _P]),
+    "picp_stage2": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), _P]),
+    "picp_stage2_reduce": (C.c_int, [_P, _P]),
+    "picp_solve": (C.c_int, [_P, _P, C.POINTER(ScheduleStruct), _P, _P, _P, C.c_int32]),
+    "picp_finish": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.POINTER(ResultStruct)]),
+    "picp_linearize": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_double,
+                                 C.c_int32, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_int64)]),
+    "picp_associate": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64,
+                                 C.POINTER(C.c_int64)]),
+    "picp_project": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), _P, _P, _P]),
+    "picp_gather_pairs": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "picp_invert_pose": (C.c_int, [_P, _P, _P]),
+    "picp_v2T": (C.c_int, [_P, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library():
+    """Loads libpicp_hip.so and declares every entry point's signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PicpError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C monocular-visual-odometry_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != PICP_OK:
+        msg = load_library().picp_last_error()
+        raise PicpError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def camera_struct(K, width, height) -> CameraStruct:
+    c = CameraStruct()
+    Kf = np.asarray(K, dtype=np.float64).reshape(9)
+    for i in range(9):
+        c.K[i] = float(Kf[i])
+    c.width = float(width)
+    c.height = float(height)
+    return c
+
+
+def schedule_struct(num_iterations, min_inliers, kernel_threshold, min_kernel_threshold, max_kernel_threshold,
+                    damping, min_damping, max_damping, disable_stop=False) -> ScheduleStruct:
+    s = ScheduleStruct()
+    s.num_iterations = int(num_iterations)
+    s.min_inliers = int(min_inliers)
+    s.kernel_threshold = float(kernel_threshold)
+    s.min_kernel_threshold = float(min_kernel_threshold)
+    s.max_kernel_threshold = float(max_kernel_threshold)
+    s.damping = float(damping)
+    s.min_damping = float(min_damping)
+    s.max_damping = float(max_damping)
+    s.disable_stop = 1 if disable_stop else 0
+    s.reserved = 0
+    return s
+
+
+def _pad32(n):
+    """Plane stride (in doubles) that keeps every SoA plane 256-byte aligned, so the scans use 16-byte loads."""
+    return max((int(n) + 31) // 32 * 32, 32)
+
+
+def _host16(T):
+    a = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(16))
+    return a, a.ctypes.data_as(_P)
+
+
+class Context:
+    """One picp_ctx: a device, the torch stream current at creation, and the reduction workspace."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise PicpError("no HIP device visible to PyTorch; the projective-ICP kernels need an MI355X (gfx950)")
+        self.torch = torch
+        self.lib = load_library()
+        self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            handle = _P()
+            check(self.lib.picp_create(C.byref(handle), self.device.index, _P(stream)), "picp_create")
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.picp_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- plumbing ----------------------------------------------------------------------------
+    def to_device(self, a, dtype=np.float64):
+        """Host array -> contiguous device tensor (float64 unless told otherwise)."""
+        t = self.torch
+        if isinstance(a, t.Tensor):
+            want = {np.float64: t.float64, np.int64: t.int64, np.uint8: t.uint8}[dtype]
+            return a.to(device=self.device, dtype=want).contiguous()
+        return t.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).to(self.device)
+
+    def empty(self, shape, dtype="float64"):
+        t = self.torch
+        return t.empty(shape, dtype=getattr(t, dtype), device=self.device)
+
+    def zeros(self, shape, dtype="float64"):
+        t = self.torch
+        return t.zeros(shape, dtype=getattr(t, dtype), device=self.device)
+
+    @staticmethod
+    def ptr(tensor):
+        return _P(tensor.data_ptr()) if tensor is not None else _P(0)
+
+    def use_current_stream(self):
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.picp_set_stream(self.handle, _P(stream)), "picp_set_stream")
+
+    def synchronize(self):
+        check(self.lib.picp_synchronize(self.handle), "picp_synchronize")
+
+    def soa(self, uv, pw):
+        """(M,2) pixels + (M,3) points -> five contiguous device arrays u, v, x, y, z."""
+        uv = np.asarray(uv, dtype=np.float64).reshape(-1, 2)
+        pw = np.asarray(pw, dtype=np.float64).reshape(-1, 3)
+        if uv.shape[0] != pw.shape[0]:
+            raise ValueError(f"{uv.shape[0]} image points but {pw.shape[0]} world points")
+        M = uv.shape[0]
+        planes = np.zeros((5, _pad32(M)))                       # plane stride padded: every plane 256-B aligned
+        planes[:2, :M] = uv.T
+        planes[2:, :M] = pw.T
+        d = self.to_device(planes)
+        return [d[k][:M] for k in range(5)]
+
+    # ---- loop ----------------------------------------------------------------------------------
+    def run(self, corr, w_T_c0, cam: CameraStruct, sched: ScheduleStruct, want_history=True):
+        """picp_run on device arrays corr = [u, v, x, y, z].  Returns (ResultStruct, history ndarray)."""
+        M = int(corr[0].numel())
+        state = self.empty(STATE_DOUBLES)
+        rows = max(int(sched.num_iterations), 1)
+        hist = self.zeros((rows, HIST_STRIDE)) if want_history else None
+        res = ResultStruct()
+        pose, pose_p = _host16(w_T_c0)
+        check(self.lib.picp_run(self.handle, *[self.ptr(c) for c in corr], M, pose_p, C.byref(cam), C.byref(sched),
+                                self.ptr(state), self.ptr(hist), rows if want_history else 0, C.byref(res)),
+              "picp_run")
+        h = hist[: res.num_iterations].cpu().numpy() if want_history else None
+        return res, h
+
+    def run_batched(self, corr, offsets, poses0, cam: CameraStruct, sched: ScheduleStruct, want_history=False):
+        """picp_run_batched.  offsets: int64 device tensor [B+1]; poses0: device [B,16].
+        Returns (results tensor [B, RESULT_DOUBLES] viewed as float64, history tensor or None); does not sync."""
+        B = int(offsets.numel()) - 1
+        results = self.empty((B, RESULT_DOUBLES))
+        rows = max(int(sched.num_iterations), 1)
+        hist = self.zeros((B, rows, HIST_STRIDE)) if want_history else None
+        check(self.lib.picp_run_batched(self.handle, *[self.ptr(c) for c in corr], self.ptr(offsets), B,
+                                        self.ptr(poses0), C.byref(cam), C.byref(sched), self.ptr(results),
+                                        self.ptr(hist), rows if want_history else 0), "picp_run_batched")
+        return results, hist
+
+    @staticmethod
+    def decode_results(results_host: np.ndarray):
+        """[B, RESULT_DOUBLES] float64 host array -> dict of arrays (T, valid, num_iterations, best_index, best_error)."""
+        raw = np.ascontiguousarray(results_host)
+        ints = raw[:, 16:18].copy().view(np.int32).reshape(-1, 4)
+        return {"T": raw[:, :16].reshape(-1, 4, 4).copy(), "valid": ints[:, 0].astype(bool),
+                "num_iterations": ints[:, 1].copy(), "best_index": ints[:, 2].copy(), "best_error": raw[:, 18].copy()}
+
+    def linearize(self, corr, w_T_c0, cam: CameraStruct, kernel_threshold, min_inliers):
+        M = int(corr[0].numel())
+        H = np.zeros(36)
+        b = np.zeros(6)
+        n, err, nin = C.c_int64(), C.c_double(), C.c_int64()
+        pose, pose_p = _host16(w_T_c0)
+        check(self.lib.picp_linearize(self.handle, *[self.ptr(c) for c in corr], M, pose_p, C.byref(cam),
+                                      float(kernel_threshold), int(min_inliers), H.ctypes.data_as(_P),
+                                      b.ctypes.data_as(_P), C.byref(n), C.byref(err), C.byref(nin)), "picp_linearize")
+        return H.reshape(6, 6), b, int(n.value), float(err.value), int(nin.value)
+
+    # ---- association ---------------------------------------------------------------------------
+    def associate(self, app1, app2, capacity=None):
+        """Device descriptor tensors [N1,D], [N2,D] -> (idx1, idx2) int64 device tensors, query-major order."""
+        N1, N2 = int(app1.shape[0]), int(app2.shape[0])
+        if N1 == 0 or N2 == 0:
+            e = self.empty(0, "int64")
+            return e, e.clone()
+        D = int(app1.shape[1])
+        if int(app2.shape[1]) != D:
+            raise ValueError(f"descriptor widths differ: {D} vs {int(app2.shape[1])}")
+        cap = int(capacity) if capacity is not None else max(N1, 1)
+        while True:
+            idx1 = self.empty(cap, "int64")
+            idx2 = self.empty(cap, "int64")
+            count = C.c_int64()
+            rc = self.lib.picp_associate(self.handle, self.ptr(app1), N1, self.ptr(app2), N2, D, self.ptr(idx1),
+                                         self.ptr(idx2), cap, C.byref(count))
+            if rc == PICP_ERR_CAPACITY:
+                cap = int(count.value)
+                continue
+            check(rc, "picp_associate")
+            n = int(count.value)
+            return idx1[:n], idx2[:n]
+
+    def gather_pairs(self, idx1, idx2, pos1, pos2):
+        n = int(idx1.numel())
+        out = self.empty((5, _pad32(n)))
+        check(self.lib.picp_gather_pairs(self.handle, self.ptr(idx1), self.ptr(idx2), n, self.ptr(pos1), self.ptr(pos2),
+                                         *[self.ptr(out[k]) for k in range(5)]), "picp_gather_pairs")
+        return [out[k][:n] for k in range(5)]
+
+    def project(self, xyz, c_T_w, cam: CameraStruct):
+        """xyz: device [3, N] planes.  Returns (inside uint8 [N], u [N], v [N]) device tensors."""
+        N = int(xyz.shape[1])
+        inside = self.empty(max(N, 1), "uint8")
+        uv = self.empty((2, max(N, 1)))
+        pose, pose_p = _host16(c_T_w)
+        check(self.lib.picp_project(self.handle, self.ptr(xyz[0]), self.ptr(xyz[1]), self.ptr(xyz[2]), N, pose_p,
+                                    C.byref(cam), self.ptr(inside), self.ptr(uv[0]), self.ptr(uv[1])), "picp_project")
+        return inside[:N], uv[0][:N], uv[1][:N]
+
+    def invert_pose(self, T):
+        a, ap = _host16(T)
+        out = np.zeros(16)
+        check(self.lib.picp_invert_pose(self.handle, ap, out.ctypes.data_as(_P)), "picp_invert_pose")
+        return out.reshape(4, 4)
+
+    def v2T(self, v):
+        a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(6))
+        out = np.zeros(16)
+        check(self.lib.picp_v2T(self.handle, a.ctypes.data_as(_P), out.ctypes.data_as(_P)), "picp_v2T")
+        return out.reshape(4, 4)
+
+
+_contexts = {}
+
+
+def get_context(device=0) -> Context:
+    """Process-wide context per device (created on first use)."""
+    key = int(device)
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = Context(key)
+        _contexts[key] = ctx
+    ctx.use_current_stream()
+    return ctx

@@ -1,0 +1,345 @@
+// Appearance association (src/data_association.py:3-57), camera projection of point sets
+// (src/Camera.py:82-137) and the pair gather, on gfx950.
+//
+// The reference matches descriptors by Python list equality: every component equal under float
+// comparison, all equal pairs reported, query-major order.  That is an all-pairs test, and it is
+// kept all-pairs here.  What is tuned is the per-pair cost: equal doubles have equal low 32-bit
+// words (+0.0 and -0.0 differ only in the high word, and NaN is excluded by the full test), so
+// each pair is first screened with one 32-bit integer compare of component 0's low word; only
+// the pairs that pass (true matches plus a 2^-32 fraction of the rest) get the full float
+// comparison of all D components.  Set-2 screening keys are staged through LDS in tiles and read
+// back as 16-byte broadcasts; each lane screens R query rows against every key it reads.
+#include "picp_common.h"
+#include "picp_device.h"
+
+namespace picp {
+
+constexpr int ANT = 256;        // threads per workgroup
+constexpr int TILE = 4096;      // set-2 keys per LDS tile (16 KiB)
+constexpr int SCAN_ITEMS = 4;   // prefix-sum elements per thread
+constexpr int SCAN_BLOCK = ANT * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t low_word(double d) { return (uint32_t)__double_as_longlong(d); }
+
+__global__ __launch_bounds__(ANT) void assoc_keys_kernel(const double* __restrict__ app, int64_t N, int D,
+                                                         uint32_t* __restrict__ key) {
+    const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    if (i < N) key[i] = low_word(app[i * D]);
+}
+
+// Full comparison of two descriptor rows (src/data_association.py:31): list equality = every
+// component equal under float ==.
+__device__ __forceinline__ bool rows_equal(const double* __restrict__ a, const double* __restrict__ b, int D) {
+    bool eq = true;
+    for (int d = 0; d < D; ++d) eq = eq && (a[d] == b[d]);
+    return eq;
+}
+
+// For each query row i: number of equal rows of set 2 and the first of them.
+template <int R>
+__global__ __launch_bounds__(ANT) void assoc_scan_kernel(const double* __restrict__ app1, int64_t N1,
+                                                         const double* __restrict__ app2, int64_t N2, int D,
+                                                         const uint32_t* __restrict__ key2,
+                                                         int64_t* __restrict__ count, int64_t* __restrict__ first) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[TILE];
+    uint32_t qk[R];
+    int64_t qi[R];
+    int64_t cnt[R];
+    int64_t fst[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        qi[r] = ((int64_t)blockIdx.x * R + r) * ANT + threadIdx.x;
+        qk[r] = (qi[r] < N1) ? low_word(app1[qi[r] * D]) : 0u;
+        cnt[r] = 0;
+        fst[r] = -1;
+    }
+    for (int64_t t0 = 0; t0 < N2; t0 += TILE) {
+        const int lim = (int)((N2 - t0 < TILE) ? (N2 - t0) : TILE);
+        __syncthreads();
+        for (int k = threadIdx.x; k < TILE; k += ANT) tile[k] = (k < lim) ? key2[t0 + k] : 0u;
+        __syncthreads();
+        const int lim4 = (lim + 3) & ~3;
+        for (int k = 0; k < lim4; k += 4) {
+            const uint4 kk = *reinterpret_cast<const uint4*>(&tile[k]);
+            bool hit = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                hit = hit | (qk[r] == kk.x) | (qk[r] == kk.y) | (qk[r] == kk.z) | (qk[r] == kk.w);
+            if (hit) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (qi[r] >= N1) continue;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int64_t j = t0 + k + c;
+                        if (j < N2 && qk[r] == tile[k + c] && rows_equal(app1 + qi[r] * D, app2 + j * D, D)) {
+                            if (cnt[r] == 0) fst[r] = j;
+                            cnt[r] += 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (qi[r] < N1) {
+            count[qi[r]] = cnt[r];
+            first[qi[r]] = fst[r];
+        }
+    }
+}
+
+// ---- exclusive prefix sum of int64 counts ------------------------------------------------------
+__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* lds /*ANT/64 + 1*/, int64_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < ANT / 64; ++w) {
+        if (w < wave) base += lds[w];
+        tot += lds[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(ANT) void scan_block_sums_kernel(const int64_t* __restrict__ count, int64_t N,
+                                                              int64_t* __restrict__ blocksum) {
+    __shared__ int64_t lds[ANT / 64 + 1];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < N) s += count[base + k];
+    int64_t tot;
+    (void)block_exclusive_scan(s, lds, &tot);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+// One workgroup turns blocksum[0..nb) into its exclusive scan and stores the grand total at [nb].
+__global__ __launch_bounds__(ANT) void scan_block_offsets_kernel(int64_t* __restrict__ blocksum, int64_t nb) {
+    __shared__ int64_t lds[ANT / 64 + 1];
+    int64_t carry = 0;
+    for (int64_t c0 = 0; c0 < nb; c0 += ANT) {
+        const int64_t i = c0 + threadIdx.x;
+        const int64_t v = (i < nb) ? blocksum[i] : 0;
+        int64_t tot;
+        const int64_t ex = block_exclusive_scan(v, lds, &tot);
+        if (i < nb) blocksum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) blocksum[nb] = carry;
+}
+
+__global__ __launch_bounds__(ANT) void scan_write_kernel(const int64_t* __restrict__ count, int64_t N,
+                                                         const int64_t* __restrict__ blocksum, int64_t nb,
+                                                         int64_t* __restrict__ offset) {
+    __shared__ int64_t lds[ANT / 64 + 1];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t c[SCAN_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        c[k] = (base + k < N) ? count[base + k] : 0;
+        s += c[k];
+    }
+    int64_t tot;
+    int64_t ex = block_exclusive_scan(s, lds, &tot) + blocksum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < N) offset[base + k] = ex;
+        ex += c[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) offset[N] = blocksum[nb];
+}
+
+// Emits the pairs in query-major order: row i writes its matches, in increasing j, starting at
+// offset[i].  One match (the usual case) needs no second look at set 2.
+__global__ __launch_bounds__(ANT) void assoc_emit_kernel(const double* __restrict__ app1, int64_t N1,
+                                                         const double* __restrict__ app2, int64_t N2, int D,
+                                                         const int64_t* __restrict__ count,
+                                                         const int64_t* __restrict__ first,
+                                                         const int64_t* __restrict__ offset,
+                                                         int64_t* __restrict__ idx1, int64_t* __restrict__ idx2,
+                                                         int64_t capacity) {
+    const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    if (i >= N1) return;
+    const int64_t c = count[i];
+    if (c == 0) return;
+    int64_t o = offset[i];
+    int64_t j = first[i];
+    if (o < capacity) {
+        idx1[o] = i;
+        idx2[o] = j;
+    }
+    int64_t left = c - 1;
+    for (++j, ++o; left > 0 && j < N2; ++j) {
+        if (rows_equal(app1 + i * D, app2 + j * D, D)) {
+            if (o < capacity) {
+                idx1[o] = i;
+                idx2[o] = j;
+            }
+            ++o;
+            --left;
+        }
+    }
+}
+
+// ---- projection of a point set and pair gather -------------------------------------------------
+__global__ __launch_bounds__(ANT) void project_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                      const double* __restrict__ z, int64_t N, Pose12 T, CameraK cam,
+                                                      uint8_t* __restrict__ inside, double* __restrict__ uu,
+                                                      double* __restrict__ vv) {
+    const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    if (i >= N) return;
+    const Projected p = project_point(T.m, cam, x[i], y[i], z[i]);
+    inside[i] = p.inside ? 1 : 0;
+    uu[i] = p.u;
+    vv[i] = p.v;
+}
+
+__global__ __launch_bounds__(ANT) void gather_pairs_kernel(const int64_t* __restrict__ idx1,
+                                                           const int64_t* __restrict__ idx2, int64_t n,
+                                                           const double* __restrict__ pos1,
+                                                           const double* __restrict__ pos2, double* __restrict__ u,
+                                                           double* __restrict__ v, double* __restrict__ x,
+                                                           double* __restrict__ y, double* __restrict__ z) {
+    const int64_t k = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i = idx1[k], j = idx2[k];
+    u[k] = pos1[i * 2 + 0];
+    v[k] = pos1[i * 2 + 1];
+    x[k] = pos2[j * 3 + 0];
+    y[k] = pos2[j * 3 + 1];
+    z[k] = pos2[j * 3 + 2];
+}
+
+static int ensure_assoc_workspace(picp_ctx* ctx, int64_t N1, int64_t N2) {
+    if (N1 > ctx->assoc_cap) {
+        if (ctx->assoc_count) (void)hipFree(ctx->assoc_count);
+        if (ctx->assoc_first) (void)hipFree(ctx->assoc_first);
+        if (ctx->assoc_offset) (void)hipFree(ctx->assoc_offset);
+        if (ctx->assoc_blocksum) (void)hipFree(ctx->assoc_blocksum);
+        ctx->assoc_count = ctx->assoc_first = ctx->assoc_offset = ctx->assoc_blocksum = nullptr;
+        ctx->assoc_cap = 0;
+        const int64_t cap = N1 + N1 / 4 + 1024;
+        const int64_t nb = (cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        PICP_HIP_CHECK(hipMalloc(&ctx->assoc_count, sizeof(int64_t) * cap));
+        PICP_HIP_CHECK(hipMalloc(&ctx->assoc_first, sizeof(int64_t) * cap));
+        PICP_HIP_CHECK(hipMalloc(&ctx->assoc_offset, sizeof(int64_t) * (cap + 1)));
+        PICP_HIP_CHECK(hipMalloc(&ctx->assoc_blocksum, sizeof(int64_t) * (nb + 1)));
+        ctx->assoc_cap = cap;
+    }
+    if (N2 > ctx->assoc_key_cap) {
+        if (ctx->assoc_key) (void)hipFree(ctx->assoc_key);
+        ctx->assoc_key = nullptr;
+        ctx->assoc_key_cap = 0;
+        const int64_t cap = N2 + N2 / 4 + 1024;
+        PICP_HIP_CHECK(hipMalloc(&ctx->assoc_key, sizeof(uint32_t) * cap));
+        ctx->assoc_key_cap = cap;
+    }
+    return PICP_OK;
+}
+
+} // namespace picp
+
+using namespace picp;
+
+extern "C" {
+
+int picp_associate(picp_ctx* ctx, const double* app1, int64_t N1, const double* app2, int64_t N2, int32_t D,
+                   int64_t* idx1, int64_t* idx2, int64_t capacity, int64_t* count) {
+    PICP_REQUIRE(ctx && count, "picp_associate: null argument");
+    PICP_REQUIRE(N1 >= 0 && N2 >= 0 && D >= 1 && capacity >= 0, "picp_associate: bad sizes N1=%lld N2=%lld D=%d",
+                 (long long)N1, (long long)N2, D);
+    PICP_REQUIRE((N1 == 0 || app1) && (N2 == 0 || app2), "picp_associate: null descriptor array");
+    PICP_REQUIRE(capacity == 0 || (idx1 && idx2), "picp_associate: null index array");
+    *count = 0;
+    if (N1 == 0 || N2 == 0) return PICP_OK;
+    DeviceGuard g(ctx->device);
+    if (int rc = ensure_assoc_workspace(ctx, N1, N2)) return rc;
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(assoc_keys_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, (int)D,
+                       ctx->assoc_key);
+    // Few query rows: one per lane keeps more workgroups busy; many: four per lane amortise the
+    // LDS reads of the screening keys.
+    if (N1 >= (int64_t)ANT * 4 * ctx->num_cus) {
+        constexpr int R = 4;
+        const int64_t nb = (N1 + (int64_t)ANT * R - 1) / ((int64_t)ANT * R);
+        hipLaunchKernelGGL(assoc_scan_kernel<R>, dim3((unsigned)nb), dim3(ANT), 0, s, app1, N1, app2, N2, (int)D,
+                           (const uint32_t*)ctx->assoc_key, ctx->assoc_count, ctx->assoc_first);
+    } else {
+        const int64_t nb = (N1 + ANT - 1) / ANT;
+        hipLaunchKernelGGL(assoc_scan_kernel<1>, dim3((unsigned)nb), dim3(ANT), 0, s, app1, N1, app2, N2, (int)D,
+                           (const uint32_t*)ctx->assoc_key, ctx->assoc_count, ctx->assoc_first);
+    }
+    PICP_HIP_CHECK(hipGetLastError());
+    const int64_t nb = (N1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count,
+                       N1, ctx->assoc_blocksum);
+    hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(ANT), 0, s, ctx->assoc_blocksum, nb);
+    hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count, N1,
+                       (const int64_t*)ctx->assoc_blocksum, nb, ctx->assoc_offset);
+    PICP_HIP_CHECK(hipGetLastError());
+    int64_t* h = reinterpret_cast<int64_t*>(ctx->pinned);
+    PICP_HIP_CHECK(hipMemcpyAsync(h, ctx->assoc_offset + N1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    PICP_HIP_CHECK(hipStreamSynchronize(s));
+    *count = h[0];
+    if (h[0] > capacity) {
+        set_error("picp_associate: %lld pairs found, index arrays hold %lld", (long long)h[0], (long long)capacity);
+        return PICP_ERR_CAPACITY;
+    }
+    if (h[0] > 0) {
+        hipLaunchKernelGGL(assoc_emit_kernel, dim3((unsigned)((N1 + ANT - 1) / ANT)), dim3(ANT), 0, s, app1, N1, app2,
+                           N2, (int)D, (const int64_t*)ctx->assoc_count, (const int64_t*)ctx->assoc_first,
+                           (const int64_t*)ctx->assoc_offset, idx1, idx2, capacity);
+        PICP_HIP_CHECK(hipGetLastError());
+        PICP_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return PICP_OK;
+}
+
+int picp_project(picp_ctx* ctx, const double* x, const double* y, const double* z, int64_t N,
+                 const double* c_T_w_host, const picp_camera* cam, uint8_t* inside, double* uv_u, double* uv_v) {
+    PICP_REQUIRE(ctx && c_T_w_host && cam, "picp_project: null argument");
+    PICP_REQUIRE(N >= 0, "picp_project: negative count");
+    PICP_REQUIRE(c_T_w_host[12] == 0.0 && c_T_w_host[13] == 0.0 && c_T_w_host[14] == 0.0 && c_T_w_host[15] == 1.0,
+                 "picp_project: c_T_w last row must be (0,0,0,1)");
+    if (N == 0) return PICP_OK;
+    PICP_REQUIRE(x && y && z && inside && uv_u && uv_v, "picp_project: null array");
+    DeviceGuard g(ctx->device);
+    Pose12 T;
+    for (int i = 0; i < 12; ++i) T.m[i] = c_T_w_host[i];
+    CameraK c;
+    for (int i = 0; i < 9; ++i) c.k[i] = cam->K[i];
+    c.width = cam->width;
+    c.height = cam->height;
+    hipLaunchKernelGGL(project_kernel, dim3((unsigned)((N + ANT - 1) / ANT)), dim3(ANT), 0, ctx->stream, x, y, z, N, T,
+                       c, inside, uv_u, uv_v);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+int picp_gather_pairs(picp_ctx* ctx, const int64_t* idx1, const int64_t* idx2, int64_t n, const double* pos1,
+                      const double* pos2, double* u, double* v, double* x, double* y, double* z) {
+    PICP_REQUIRE(ctx != nullptr, "picp_gather_pairs: null ctx");
+    PICP_REQUIRE(n >= 0, "picp_gather_pairs: negative count");
+    if (n == 0) return PICP_OK;
+    PICP_REQUIRE(idx1 && idx2 && pos1 && pos2 && u && v && x && y && z, "picp_gather_pairs: null array");
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)((n + ANT - 1) / ANT)), dim3(ANT), 0, ctx->stream, idx1,
+                       idx2, n, pos1, pos2, u, v, x, y, z);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+} // extern "C"

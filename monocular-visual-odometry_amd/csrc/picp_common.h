@@ -1,0 +1,73 @@
+// Host-side plumbing shared by the translation units of libpicp_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/picp_hip.h"
+
+struct picp_ctx {
+    int device;
+    hipStream_t stream;
+    int num_cus;
+    int max_blocks;   // rows of the per-workgroup partial-sum buffers
+    double* part1;    // [max_blocks][PICP_S1_DOUBLES]
+    double* part2;    // [max_blocks][PICP_S2_DOUBLES]
+    int rows1, rows2; // rows written by the last stage-1 / stage-2 launch
+    double* scratch;  // small device scratch: state block + s1 + s2 + misc (see offsets below)
+    // association workspace, grown on demand
+    int64_t* assoc_count;  // [cap] matches per query row
+    int64_t* assoc_first;  // [cap] first matching row of set 2
+    int64_t* assoc_offset; // [cap + 1] exclusive prefix sum of assoc_count
+    int64_t* assoc_blocksum;
+    uint32_t* assoc_key;   // [key_cap] low words of component 0 of set 2
+    int64_t assoc_cap;
+    int64_t assoc_key_cap;
+    double* pinned; // host-pinned staging for small read-backs
+};
+
+namespace picp {
+
+// offsets (in doubles) into ctx->scratch
+enum : int {
+    SCR_STATE = 0,                              // PICP_STATE_DOUBLES
+    SCR_S1 = 128,                               // PICP_S1_DOUBLES
+    SCR_S2 = 192,                               // PICP_S2_DOUBLES
+    SCR_MISC = 256,                             // 64 doubles for tiny test kernels
+    SCR_DOUBLES = 512,
+};
+enum : int { PINNED_DOUBLES = 4096 };
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+} // namespace picp
+
+#define PICP_HIP_CHECK(expr)                                           \
+    do {                                                               \
+        hipError_t _e = (expr);                                        \
+        if (_e != hipSuccess) return picp::hip_fail(_e, #expr);        \
+    } while (0)
+
+#define PICP_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            picp::set_error(__VA_ARGS__);  \
+            return PICP_ERR_INVALID;       \
+        }                                  \
+    } while (0)

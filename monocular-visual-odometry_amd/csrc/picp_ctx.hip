@@ -1,0 +1,98 @@
+// Context life cycle and error reporting of libpicp_hip.so.
+#include "picp_common.h"
+
+namespace picp {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return PICP_ERR_HIP;
+}
+
+} // namespace picp
+
+using namespace picp;
+
+extern "C" {
+
+int picp_version(void) { return PICP_VERSION; }
+
+const char* picp_last_error(void) { return g_error; }
+
+int picp_create(picp_ctx** out, int device, void* stream) {
+    PICP_REQUIRE(out != nullptr, "picp_create: null output pointer");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("picp_create: no HIP device is visible");
+        return PICP_ERR_NO_DEVICE;
+    }
+    PICP_REQUIRE(device >= 0 && device < ndev, "picp_create: device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    PICP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("picp_create: device %d is %s; this library carries gfx950 (MI355X) code only", device,
+                  prop.gcnArchName);
+        return PICP_ERR_NO_DEVICE;
+    }
+    DeviceGuard g(device);
+    picp_ctx* ctx = new picp_ctx();
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device;
+    ctx->stream = static_cast<hipStream_t>(stream);
+    ctx->num_cus = prop.multiProcessorCount;
+    // Two workgroups of 256 threads per CU: the second scan keeps ~120 accumulator registers per
+    // lane, which leaves room for two waves per SIMD.
+    ctx->max_blocks = 2 * ctx->num_cus;
+    hipError_t e = hipMalloc(&ctx->part1, sizeof(double) * PICP_S1_DOUBLES * ctx->max_blocks);
+    if (e == hipSuccess) e = hipMalloc(&ctx->part2, sizeof(double) * PICP_S2_DOUBLES * ctx->max_blocks);
+    if (e == hipSuccess) e = hipMalloc(&ctx->scratch, sizeof(double) * SCR_DOUBLES);
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, sizeof(double) * PINNED_DOUBLES, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemset(ctx->scratch, 0, sizeof(double) * SCR_DOUBLES);
+    if (e != hipSuccess) {
+        picp_destroy(ctx);
+        return hip_fail(e, "picp_create allocations");
+    }
+    *out = ctx;
+    return PICP_OK;
+}
+
+int picp_destroy(picp_ctx* ctx) {
+    if (ctx == nullptr) return PICP_OK;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->part1) (void)hipFree(ctx->part1);
+    if (ctx->part2) (void)hipFree(ctx->part2);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->assoc_count) (void)hipFree(ctx->assoc_count);
+    if (ctx->assoc_first) (void)hipFree(ctx->assoc_first);
+    if (ctx->assoc_offset) (void)hipFree(ctx->assoc_offset);
+    if (ctx->assoc_blocksum) (void)hipFree(ctx->assoc_blocksum);
+    if (ctx->assoc_key) (void)hipFree(ctx->assoc_key);
+    delete ctx;
+    return PICP_OK;
+}
+
+int picp_set_stream(picp_ctx* ctx, void* stream) {
+    PICP_REQUIRE(ctx != nullptr, "picp_set_stream: null ctx");
+    ctx->stream = static_cast<hipStream_t>(stream);
+    return PICP_OK;
+}
+
+int picp_synchronize(picp_ctx* ctx) {
+    PICP_REQUIRE(ctx != nullptr, "picp_synchronize: null ctx");
+    DeviceGuard g(ctx->device);
+    PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PICP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,576 @@
+// Device-side math shared by every kernel of libpicp_hip.so (gfx950 only).
+//
+// All arithmetic is float64.  The functions restate, per correspondence and per iteration,
+// what the reference computes in numpy; each one names the reference lines it follows
+// (paths relative to the reference checkout).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/picp_hip.h"
+
+namespace picp {
+
+// ---- layout of the device state block (PICP_STATE_DOUBLES doubles) -------------------------
+// The loop's scalar state (src/ProjectiveICP.py:157-171) lives in device memory so iterations
+// chain without a host round trip.
+enum : int {
+    ST_W_T_C = 0,        // [16] current pose w_T_c0
+    ST_C_T_W = 16,       // [16] its inverse = the camera state c_T_w (:232)
+    ST_THR = 32,         // kernel_threshold
+    ST_LAMBDA = 33,      // dumping_factor
+    ST_ERR_PREV = 34,    // error_prev
+    ST_MEAN_SLOPE = 35,  // error_mean_slope
+    ST_SIGMA_SLOPE = 36, // error_sigma_slope
+    ST_STUCK = 37,       // stuck_counter
+    ST_FLICKER = 38,     // flickering_counter
+    ST_IT = 39,          // iterations completed (icp_iteration)
+    ST_STOP = 40,        // 1 once the stop test fired or num_iterations was reached
+    ST_RING = 41,        // [10] error_slope_ring_buffer
+    ST_BEST_ERR = 51,    // running minimum of the error list (first minimum wins, :249)
+    ST_BEST_IT = 52,     // its index
+    ST_BEST_T = 64,      // [16] pose of that iteration (:254)
+    ST_START_T = 80,     // [16] pose on entry, returned when the result is invalid (:251)
+};
+
+// stage-1 record
+enum : int { S1_SUM_CHI = 0, S1_COUNT = 1, S1_N_INSIDE = 2, S1_PAD = 3 };
+// stage-2 record: two candidate inlier sets, F = {chi < mean} and R = stage-1 survivors not in F.
+// The reference uses F when it has >= min_inliers members, else F u R (:307-310).
+enum : int {
+    S2_HF = 0,    // [21] upper triangle of sum J^T J over F, row-major (00,01,..,05,11,..,55)
+    S2_BF = 21,   // [6]  sum J^T e over F
+    S2_CHI_F = 27,
+    S2_N_F = 28,
+    S2_HR = 29,   // [21] same over R
+    S2_BR = 50,   // [6]
+    S2_CHI_R = 56,
+    S2_N_R = 57,
+    S2_USED = 58, // number of meaningful entries; the record is padded to PICP_S2_DOUBLES
+};
+
+struct CameraK {
+    double k[9];
+    double width, height;
+};
+struct Pose12 { // rows 0..2 of a 4x4 pose, passed to kernels by value
+    double m[12];
+};
+
+__device__ __forceinline__ double d_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+// ---- Camera.project_point (src/Camera.py:104-119) -------------------------------------------
+// T = c_T_w rows 0..2 (12 doubles).  The reference also forms the homogeneous w and divides by
+// it; every pose it builds has last row (0,0,0,1), so w == 1 exactly and the division is the
+// identity.  Order follows the reference: both pixel divisions happen before any test, then
+// "z <= 0 -> outside", then the four image-bound tests.  Tests are written as negations of the
+// reference's reject conditions so that NaN behaves as in Python (a NaN coordinate rejects
+// nothing).
+struct Projected {
+    double pcx, pcy, pcz; // point in camera coordinates
+    double h0, h1, h2;    // K @ pc
+    double u, v;
+    bool inside;
+};
+
+__device__ __forceinline__ Projected project_point(const double* __restrict__ T, const CameraK& cam, double x,
+                                                   double y, double z) {
+    Projected p;
+    p.pcx = T[0] * x + T[1] * y + T[2] * z + T[3];
+    p.pcy = T[4] * x + T[5] * y + T[6] * z + T[7];
+    p.pcz = T[8] * x + T[9] * y + T[10] * z + T[11];
+    p.h0 = cam.k[0] * p.pcx + cam.k[1] * p.pcy + cam.k[2] * p.pcz;
+    p.h1 = cam.k[3] * p.pcx + cam.k[4] * p.pcy + cam.k[5] * p.pcz;
+    p.h2 = cam.k[6] * p.pcx + cam.k[7] * p.pcy + cam.k[8] * p.pcz;
+    p.u = p.h0 / p.h2;
+    p.v = p.h1 / p.h2;
+    const bool behind = (p.pcz <= 0.0);
+    const bool outside = (p.u < 0.0) || (p.u >= cam.width) || (p.v < 0.0) || (p.v >= cam.height);
+    p.inside = !behind && !outside;
+    return p;
+}
+
+// ---- __error_and_jacobian (src/ProjectiveICP.py:326-353) ------------------------------------
+// J = J_proj @ K @ J_icp with J_icp = [I | -skew(p_hat)] (:341-343) and
+// J_proj = [[1/z, 0, -x/z^2], [0, 1/z, -y/z^2]] on p_hat_cam = K p_hat (:345-349).
+// p_hat is the point in camera coordinates (:336-337) -- the same transform as the projection,
+// because the camera state is inv(w_T_c0) (:232).
+__device__ __forceinline__ void jacobian_rows(const Projected& p, const CameraK& cam, double (&J0)[6],
+                                              double (&J1)[6]) {
+    const double zi = 1.0 / p.h2;  // :345
+    const double zi2 = zi * zi;    // :346
+    const double m0 = -p.h0 * zi2; // :348
+    const double m1 = -p.h1 * zi2; // :349
+    // A = J_proj @ K  (2x3)
+    const double a00 = zi * cam.k[0] + m0 * cam.k[6];
+    const double a01 = zi * cam.k[1] + m0 * cam.k[7];
+    const double a02 = zi * cam.k[2] + m0 * cam.k[8];
+    const double a10 = zi * cam.k[3] + m1 * cam.k[6];
+    const double a11 = zi * cam.k[4] + m1 * cam.k[7];
+    const double a12 = zi * cam.k[5] + m1 * cam.k[8];
+    // J = A @ [I | -skew(p)],  -skew(p) = [[0, pz, -py], [-pz, 0, px], [py, -px, 0]]
+    J0[0] = a00;
+    J0[1] = a01;
+    J0[2] = a02;
+    J0[3] = a02 * p.pcy - a01 * p.pcz;
+    J0[4] = a00 * p.pcz - a02 * p.pcx;
+    J0[5] = a01 * p.pcx - a00 * p.pcy;
+    J1[0] = a10;
+    J1[1] = a11;
+    J1[2] = a12;
+    J1[3] = a12 * p.pcy - a11 * p.pcz;
+    J1[4] = a10 * p.pcz - a12 * p.pcx;
+    J1[5] = a11 * p.pcx - a10 * p.pcy;
+}
+
+// Sums of one candidate inlier set: upper triangle of H, b, sum of chi, member count.
+struct SetSums {
+    double H[21];
+    double b[6];
+    double chi;
+    unsigned n;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < 21; ++i) H[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) b[i] = 0.0;
+        chi = 0.0;
+        n = 0u;
+    }
+    // H += J^T J, b += J^T e  (src/ProjectiveICP.py:316-317)
+    __device__ __forceinline__ void add(const double (&J0)[6], const double (&J1)[6], double e0, double e1,
+                                        double c) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                H[k] += J0[i] * J0[j] + J1[i] * J1[j];
+                ++k;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) b[i] += J0[i] * e0 + J1[i] * e1;
+        chi += c;
+        n += 1u;
+    }
+};
+
+// ---- wavefront (64 lanes) and workgroup sums -------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sums NV per-thread values over a workgroup of NT threads (NT a multiple of 64, <= 1024).
+// lds: at least (NT/64)*NV doubles.  On return every thread of wave 0 with tid < NV holds the
+// workgroup total of value tid in `out` (other threads: unspecified).  The order of additions is
+// fixed (butterfly inside a wave, then waves 0,1,2,.. in order), so results are reproducible.
+template <int NV, int NT>
+__device__ __forceinline__ double block_sum(const double (&vals)[NV], double* lds) {
+    static_assert(NV <= 64, "one lane of wave 0 per value");
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double s = wave_sum(vals[i]);
+        if (lane == 0) lds[wave * NV + i] = s;
+    }
+    __syncthreads();
+    double out = 0.0;
+    if (threadIdx.x < NV) {
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) out += lds[w * NV + threadIdx.x];
+    }
+    __syncthreads();
+    return out;
+}
+
+// Folds `rows` partial records of NV doubles (row stride `stride`) into totals, rows added in
+// index order per column group so the result does not depend on scheduling.  Every thread with
+// tid < NV of a workgroup of NT threads returns the total of column tid.
+// lds: at least NT doubles.
+template <int NV, int NT>
+__device__ __forceinline__ double fold_partials(const double* __restrict__ part, int rows, int stride,
+                                                double* lds) {
+    static_assert(NV <= 64 && NT % 64 == 0, "column per lane");
+    constexpr int G = NT / 64; // row groups
+    const int col = threadIdx.x & 63;
+    const int grp = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (col < NV) {
+        for (int r = grp; r < rows; r += G) acc += part[(size_t)r * stride + col];
+    }
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    double out = 0.0;
+    if (threadIdx.x < NV) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) out += lds[g * 64 + threadIdx.x];
+    }
+    __syncthreads();
+    return out;
+}
+
+// ---- small dense routines used by the solve (one lane) ---------------------------------------
+
+// General 4x4 inverse by LU with partial pivoting applied to the identity, the algorithm behind
+// np.linalg.inv (LAPACK gesv) used at src/ProjectiveICP.py:232.  A rigid-transform shortcut
+// [R^T | -R^T t] is not usable: R is built from float32 sines and cosines
+// (src/geometry_utils.py:41) and is orthonormal only to ~1e-8.
+__device__ inline void invert4x4(const double* A, double* Ainv) {
+    double a[4][4], b[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[i][j] = A[i * 4 + j];
+            b[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        double best = fabs(a[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r) {
+            const double c = fabs(a[r][k]);
+            if (c > best) {
+                best = c;
+                p = r;
+            }
+        }
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r) {
+            if (r == p) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double t = a[k][j];
+                    a[k][j] = a[r][j];
+                    a[r][j] = t;
+                    t = b[k][j];
+                    b[k][j] = b[r][j];
+                    b[r][j] = t;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r) {
+            const double f = a[r][k] / a[k][k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j > k) a[r][j] -= f * a[k][j];
+                b[r][j] -= f * b[k][j];
+            }
+            a[r][k] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            double s = b[i][j];
+#pragma unroll
+            for (int k = i + 1; k < 4; ++k) s -= a[i][k] * b[k][j];
+            b[i][j] = s / a[i][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ainv[i * 4 + j] = b[i][j];
+}
+
+// Solves (H + lambda I) dx = -b for symmetric positive definite H + lambda I by Cholesky.
+// The reference calls np.linalg.lstsq (src/ProjectiveICP.py:269-270); the damped matrix is SPD
+// (lambda >= min damping > 0), so the least-squares solution is the unique solution.
+__device__ inline void damped_solve6(const double* H /*36, symmetric*/, const double* b, double lambda, double* dx) {
+    double L[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = H[i * 6 + j] + ((i == j) ? lambda : 0.0);
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j)
+                L[i][i] = sqrt(s);
+            else
+                L[i][j] = s / L[j][j];
+        }
+    }
+    double yv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = -b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i][k] * yv[k];
+        yv[i] = s / L[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = yv[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * dx[k];
+        dx[i] = s / L[i][i];
+    }
+}
+
+// v2T (src/geometry_utils.py:38-45): translation copied; R = Rx Ry Rz (:19-23) where the angles
+// are first cast to float32 (:41) so each sine/cosine is a float32 value, widened to float64
+// before the two 3x3 products.  float32 sin/cos are taken as the float64 result rounded to
+// float32 (what numpy returns for these magnitudes).
+__device__ inline void v2T_device(const double* v, double* T) {
+    const float ax = (float)v[3], ay = (float)v[4], az = (float)v[5];
+    const double cx = (double)(float)cos((double)ax), sx = (double)(float)sin((double)ax);
+    const double cy = (double)(float)cos((double)ay), sy = (double)(float)sin((double)ay);
+    const double cz = (double)(float)cos((double)az), sz = (double)(float)sin((double)az);
+    const double Rx[9] = {1.0, 0.0, 0.0, 0.0, cx, -sx, 0.0, sx, cx};
+    const double Ry[9] = {cy, 0.0, sy, 0.0, 1.0, 0.0, -sy, 0.0, cy};
+    const double Rz[9] = {cz, -sz, 0.0, sz, cz, 0.0, 0.0, 0.0, 1.0};
+    double Rxy[9], R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Rxy[i * 3 + j] = Rx[i * 3 + 0] * Ry[0 * 3 + j] + Rx[i * 3 + 1] * Ry[1 * 3 + j] + Rx[i * 3 + 2] * Ry[2 * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            R[i * 3 + j] = Rxy[i * 3 + 0] * Rz[0 * 3 + j] + Rxy[i * 3 + 1] * Rz[1 * 3 + j] + Rxy[i * 3 + 2] * Rz[2 * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = v[i];
+    }
+    T[12] = 0.0;
+    T[13] = 0.0;
+    T[14] = 0.0;
+    T[15] = 1.0;
+}
+
+__device__ inline void matmul4(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            C[i * 4 + j] = A[i * 4 + 0] * B[0 * 4 + j] + A[i * 4 + 1] * B[1 * 4 + j] + A[i * 4 + 2] * B[2 * 4 + j] +
+                           A[i * 4 + 3] * B[3 * 4 + j];
+}
+
+// np.add.reduce over 10 contiguous doubles: numpy's pairwise summation keeps 8 running sums for
+// the first 8 elements, combines them as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and then adds the
+// remaining elements one by one.  np.mean / np.std at src/ProjectiveICP.py:212-213 go through it.
+__device__ inline double numpy_sum10(const double* a) {
+    double s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    s += a[8];
+    s += a[9];
+    return s;
+}
+
+struct StepRecord {
+    double H[36];
+    double b[6];
+    double dx[6];
+    double error;
+    double n_inliers, n_inside, n_stage1, n_stage2, used_stage2, mean_stage1, done;
+};
+
+// One iteration's serial tail, run by a single lane: choose the inlier set
+// (src/ProjectiveICP.py:300-321), damped solve and pose update (:269-271), schedules (:200-228),
+// state update and history row (:231-238).
+// st: the state block (read and written).  s1/s2: the reduced stage records.
+// hist_row: this iteration's history row or nullptr.
+__device__ inline void solve_and_schedule(double* st, const double* s1, const double* s2, const picp_schedule& sc,
+                                          double* hist_row) {
+    const double n_inside = s1[S1_N_INSIDE];
+    const double n1 = s1[S1_COUNT];
+    StepRecord r;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) r.H[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        r.b[i] = 0.0;
+        r.dx[i] = 0.0;
+    }
+    r.n_inside = n_inside;
+    r.n_stage1 = n1;
+    r.n_stage2 = 0.0;
+    r.used_stage2 = 0.0;
+    r.mean_stage1 = 0.0;
+    double T1[16];
+    const double lambda = st[ST_LAMBDA];
+    double thr = st[ST_THR];
+    if (n_inside == 0.0) {
+        // __one_step returns before the solve when there are no points (:263)
+        r.done = 0.0;
+        r.error = d_inf();
+        r.n_inliers = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T1[i] = st[ST_W_T_C + i];
+    } else {
+        r.done = 1.0;
+        if (n1 == 0.0) { // :300
+            r.n_inliers = 0.0;
+            r.error = d_inf();
+        } else {
+            r.mean_stage1 = s1[S1_SUM_CHI] / n1;
+            const double nf = s2[S2_N_F], nr = s2[S2_N_R];
+            r.n_stage2 = nf;
+            const bool use_f = (nf >= (double)sc.min_inliers); // :307
+            r.used_stage2 = use_f ? 1.0 : 0.0;
+            double chi_sum;
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = i; j < 6; ++j) {
+                    const double h = use_f ? s2[S2_HF + k] : (s2[S2_HF + k] + s2[S2_HR + k]);
+                    r.H[i * 6 + j] = h;
+                    r.H[j * 6 + i] = h;
+                    ++k;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) r.b[i] = use_f ? s2[S2_BF + i] : (s2[S2_BF + i] + s2[S2_BR + i]);
+            if (use_f) {
+                r.n_inliers = nf;
+                chi_sum = s2[S2_CHI_F];
+            } else {
+                r.n_inliers = nf + nr;
+                chi_sum = s2[S2_CHI_F] + s2[S2_CHI_R];
+            }
+            r.error = (r.n_inliers > 0.0) ? chi_sum / r.n_inliers : d_inf(); // :319-321
+        }
+        damped_solve6(r.H, r.b, lambda, r.dx); // :269-270
+        double dT[16];
+        v2T_device(r.dx, dT);
+        matmul4(st + ST_W_T_C, dT, T1); // :271
+    }
+
+    // kernel threshold schedule (:200-205)
+    if (r.n_inliers == n_inside) {
+        thr = sc.min_kernel_threshold;
+    } else if (r.n_inliers < (double)sc.min_inliers) {
+        if (thr + 10.0 <= sc.max_kernel_threshold) thr += 10.0;
+    } else {
+        if (thr - 10.0 >= sc.min_kernel_threshold) thr -= 10.0;
+    }
+
+    // error slope statistics (:208-213); `it` is 1-based as in the reference (:179)
+    const int it = (int)st[ST_IT] + 1;
+    const double error_prev = st[ST_ERR_PREV];
+    double mean_slope = st[ST_MEAN_SLOPE], sigma_slope = st[ST_SIGMA_SLOPE];
+    if (it > 1) {
+        const double inf = d_inf();
+        const double slope = (r.error == inf || error_prev == inf) ? 1e3 : fabs(error_prev - r.error);
+        double ring[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) ring[i] = st[ST_RING + i];
+        const int slot = it % 10;
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+            if (i == slot) ring[i] = slope;
+        st[ST_RING + slot] = slope;
+        mean_slope = numpy_sum10(ring) / 10.0; // np.mean
+        double dev[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const double d = ring[i] - mean_slope;
+            dev[i] = d * d;
+        }
+        sigma_slope = sqrt(numpy_sum10(dev) / 10.0); // np.std (population)
+    }
+    const bool done = (r.done != 0.0);
+    double stuck = st[ST_STUCK], flicker = st[ST_FLICKER];
+    stuck = (done && mean_slope < 1e-2 && sigma_slope < 1e-2) ? stuck + 1.0 : 0.0; // :216-217
+    flicker = (done && mean_slope > 1.0 && sigma_slope > 1.0) ? flicker + 1.0 : 0.0; // :220-221
+
+    // damping schedule (:224-225), limit = 10 (:164)
+    double lam = lambda;
+    if ((lam / 2.0) >= sc.min_damping && (stuck > 10.0 || (stuck == 0.0 && flicker == 0.0))) lam /= 2.0;
+    if ((lam * 2.0) <= sc.max_damping && flicker > 10.0) lam *= 2.0;
+
+    bool stop = done && (r.error < 0.01 || stuck > 100.0) && (sc.disable_stop == 0); // :228
+    if (it >= sc.num_iterations) stop = true;                                        // :178
+
+    // state update (:231-238)
+    double Tinv[16];
+    invert4x4(T1, Tinv);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        st[ST_W_T_C + i] = T1[i];
+        st[ST_C_T_W + i] = Tinv[i];
+    }
+    st[ST_THR] = thr;
+    st[ST_LAMBDA] = lam;
+    st[ST_ERR_PREV] = r.error;
+    st[ST_MEAN_SLOPE] = mean_slope;
+    st[ST_SIGMA_SLOPE] = sigma_slope;
+    st[ST_STUCK] = stuck;
+    st[ST_FLICKER] = flicker;
+    st[ST_IT] = (double)it;
+    st[ST_STOP] = stop ? 1.0 : 0.0;
+    // np.argmin returns the first minimum; NaN would win in numpy, which cannot arise here
+    // because a NaN chi never passes chi <= threshold.
+    if (it == 1 || r.error < st[ST_BEST_ERR]) {
+        st[ST_BEST_ERR] = r.error;
+        st[ST_BEST_IT] = (double)(it - 1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[ST_BEST_T + i] = T1[i];
+    }
+
+    if (hist_row != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hist_row[PICP_H_T + i] = T1[i];
+        hist_row[PICP_H_ERROR] = r.error;
+        hist_row[PICP_H_NUM_INLIERS] = r.n_inliers;
+        hist_row[PICP_H_KERNEL_THR] = thr;
+        hist_row[PICP_H_DAMPING] = lam;
+        hist_row[PICP_H_N_INSIDE] = r.n_inside;
+        hist_row[PICP_H_DONE] = r.done;
+        hist_row[PICP_H_N_STAGE1] = r.n_stage1;
+        hist_row[PICP_H_N_STAGE2] = r.n_stage2;
+        hist_row[PICP_H_USED_STAGE2] = r.used_stage2;
+        hist_row[PICP_H_MEAN_STAGE1] = r.mean_stage1;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            hist_row[PICP_H_DX + i] = r.dx[i];
+            hist_row[PICP_H_B + i] = r.b[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 36; ++i) hist_row[PICP_H_H + i] = r.H[i];
+        for (int i = PICP_H_H + 36; i < PICP_HIST_STRIDE; ++i) hist_row[i] = 0.0;
+    }
+}
+
+// Loop entry (src/ProjectiveICP.py:157-171): pose, camera state, base threshold and damping,
+// cleared slope statistics and counters.
+__device__ inline void init_state(double* st, const double* pose, double thr, double lambda, int num_iterations) {
+    double inv[16];
+    invert4x4(pose, inv);
+    for (int i = ST_BEST_IT + 1; i < PICP_STATE_DOUBLES; ++i) st[i] = 0.0;
+    for (int i = 0; i < 16; ++i) {
+        st[ST_W_T_C + i] = pose[i];
+        st[ST_C_T_W + i] = inv[i];
+        st[ST_BEST_T + i] = pose[i];
+        st[ST_START_T + i] = pose[i];
+    }
+    st[ST_THR] = thr;
+    st[ST_LAMBDA] = lambda;
+    st[ST_ERR_PREV] = d_inf();
+    st[ST_MEAN_SLOPE] = 0.0;
+    st[ST_SIGMA_SLOPE] = 0.0;
+    st[ST_STUCK] = 0.0;
+    st[ST_FLICKER] = 0.0;
+    st[ST_IT] = 0.0;
+    st[ST_STOP] = (num_iterations <= 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 10; ++i) st[ST_RING + i] = 0.0;
+    st[ST_BEST_ERR] = d_inf();
+    st[ST_BEST_IT] = 0.0;
+}
+
+} // namespace picp

@@ -1,0 +1,577 @@
+// Projective-ICP pose loop on gfx950: the two streaming scans over the correspondences, the
+// single-lane solve + schedule step, the whole-loop-in-one-workgroup batched kernel, and the
+// C ABI around them (include/picp_hip.h).
+//
+// Per iteration the reference needs a global mean of chi before it can decide which
+// correspondences enter H and b (src/ProjectiveICP.py:301-310), so an iteration is two scans:
+//   stage 1: in-image test, chi, {sum chi, count} of chi <= threshold            40 B / pair
+//   stage 2: mean filter, Jacobian, H/b sums of both candidate inlier sets       40 B / pair
+// Both are HBM-bound streams of five float64 arrays; every workgroup leaves one record of
+// partial sums, and the next kernel in the chain folds those records in its prologue (a kernel
+// boundary is cheaper here than an in-kernel device-wide barrier).
+#include "picp_common.h"
+#include "picp_device.h"
+
+namespace picp {
+
+constexpr int NT = 256; // threads per workgroup in every kernel of this file
+
+struct Pose16 {
+    double m[16];
+};
+
+__global__ void state_init_kernel(double* st, Pose16 pose, double thr, double lambda, int num_iterations) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) init_state(st, pose.m, thr, lambda, num_iterations);
+}
+
+// ---- stage 1 --------------------------------------------------------------------------------
+struct Stage1Sums {
+    double sum_chi;
+    unsigned n1, n_inside;
+};
+
+__device__ __forceinline__ void stage1_point(const double* __restrict__ T, const CameraK& cam, double thr, double mu,
+                                             double mv, double x, double y, double z, Stage1Sums& s) {
+    const Projected p = project_point(T, cam, x, y, z);
+    const double e0 = mu - p.u, e1 = mv - p.v;         // src/ProjectiveICP.py:333
+    const double chi = e0 * e0 + e1 * e1;              // :293
+    const bool keep = p.inside && (chi <= thr);        // :290, :294
+    s.n_inside += p.inside ? 1u : 0u;
+    s.n1 += keep ? 1u : 0u;
+    s.sum_chi += keep ? chi : 0.0;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u, const double* __restrict__ v,
+                                                    const double* __restrict__ x, const double* __restrict__ y,
+                                                    const double* __restrict__ z, int64_t M,
+                                                    const double* __restrict__ state, CameraK cam,
+                                                    double* __restrict__ part) {
+    __shared__ double lds[(NT / 64) * 3];
+    if (state[ST_STOP] != 0.0) return;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = state[ST_C_T_W + i];
+    const double thr = state[ST_THR];
+    Stage1Sums s{0.0, 0u, 0u};
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (VEC == 2) {
+        const int64_t n2 = M >> 1;
+        const double2* u2 = reinterpret_cast<const double2*>(u);
+        const double2* v2 = reinterpret_cast<const double2*>(v);
+        const double2* x2 = reinterpret_cast<const double2*>(x);
+        const double2* y2 = reinterpret_cast<const double2*>(y);
+        const double2* z2 = reinterpret_cast<const double2*>(z);
+        for (int64_t i = tid; i < n2; i += stride) {
+            const double2 a = u2[i], b = v2[i], c = x2[i], d = y2[i], e = z2[i];
+            stage1_point(T, cam, thr, a.x, b.x, c.x, d.x, e.x, s);
+            stage1_point(T, cam, thr, a.y, b.y, c.y, d.y, e.y, s);
+        }
+        if ((M & 1) && tid == 0) stage1_point(T, cam, thr, u[M - 1], v[M - 1], x[M - 1], y[M - 1], z[M - 1], s);
+    } else {
+        for (int64_t i = tid; i < M; i += stride) stage1_point(T, cam, thr, u[i], v[i], x[i], y[i], z[i], s);
+    }
+    const double vals[3] = {s.sum_chi, (double)s.n1, (double)s.n_inside};
+    const double tot = block_sum<3, NT>(vals, lds);
+    if (threadIdx.x < 3) part[(size_t)blockIdx.x * PICP_S1_DOUBLES + threadIdx.x] = tot;
+    if (threadIdx.x == 3) part[(size_t)blockIdx.x * PICP_S1_DOUBLES + 3] = 0.0;
+}
+
+// ---- stage 2 --------------------------------------------------------------------------------
+__device__ __forceinline__ void stage2_point(const double* __restrict__ T, const CameraK& cam, double thr, double mean,
+                                             double mu, double mv, double x, double y, double z, SetSums& F,
+                                             SetSums& R) {
+    const Projected p = project_point(T, cam, x, y, z);
+    const double e0 = mu - p.u, e1 = mv - p.v;
+    const double chi = e0 * e0 + e1 * e1;
+    const bool keep = p.inside && (chi <= thr);
+    if (keep) {
+        double J0[6], J1[6];
+        jacobian_rows(p, cam, J0, J1);
+        if (chi < mean) // src/ProjectiveICP.py:302 (strict)
+            F.add(J0, J1, e0, e1, chi);
+        else
+            R.add(J0, J1, e0, e1, chi);
+    }
+}
+
+__device__ __forceinline__ void pack_sets(const SetSums& F, const SetSums& R, double (&vals)[S2_USED]) {
+#pragma unroll
+    for (int i = 0; i < 21; ++i) {
+        vals[S2_HF + i] = F.H[i];
+        vals[S2_HR + i] = R.H[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        vals[S2_BF + i] = F.b[i];
+        vals[S2_BR + i] = R.b[i];
+    }
+    vals[S2_CHI_F] = F.chi;
+    vals[S2_N_F] = (double)F.n;
+    vals[S2_CHI_R] = R.chi;
+    vals[S2_N_R] = (double)R.n;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(NT) void stage2_kernel(const double* __restrict__ u, const double* __restrict__ v,
+                                                    const double* __restrict__ x, const double* __restrict__ y,
+                                                    const double* __restrict__ z, int64_t M,
+                                                    const double* __restrict__ state, CameraK cam,
+                                                    const double* __restrict__ s1part, int s1rows,
+                                                    double* __restrict__ part) {
+    __shared__ double lds[(NT / 64) * S2_USED > NT ? (NT / 64) * S2_USED : NT];
+    __shared__ double s1[PICP_S1_DOUBLES];
+    if (state[ST_STOP] != 0.0) return;
+    {
+        const double tot = fold_partials<PICP_S1_DOUBLES, NT>(s1part, s1rows, PICP_S1_DOUBLES, lds);
+        if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = tot;
+        __syncthreads();
+    }
+    const double n1 = s1[S1_COUNT];
+    double* row = part + (size_t)blockIdx.x * PICP_S2_DOUBLES;
+    if (n1 == 0.0) { // nothing survived stage 1 (src/ProjectiveICP.py:300): the sums are zero
+        if (threadIdx.x < PICP_S2_DOUBLES) row[threadIdx.x] = 0.0;
+        return;
+    }
+    const double mean = s1[S1_SUM_CHI] / n1; // np.mean, :301
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = state[ST_C_T_W + i];
+    const double thr = state[ST_THR];
+    SetSums F, R;
+    F.clear();
+    R.clear();
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (VEC == 2) {
+        const int64_t n2 = M >> 1;
+        const double2* u2 = reinterpret_cast<const double2*>(u);
+        const double2* v2 = reinterpret_cast<const double2*>(v);
+        const double2* x2 = reinterpret_cast<const double2*>(x);
+        const double2* y2 = reinterpret_cast<const double2*>(y);
+        const double2* z2 = reinterpret_cast<const double2*>(z);
+        for (int64_t i = tid; i < n2; i += stride) {
+            const double2 a = u2[i], b = v2[i], c = x2[i], d = y2[i], e = z2[i];
+            stage2_point(T, cam, thr, mean, a.x, b.x, c.x, d.x, e.x, F, R);
+            stage2_point(T, cam, thr, mean, a.y, b.y, c.y, d.y, e.y, F, R);
+        }
+        if ((M & 1) && tid == 0)
+            stage2_point(T, cam, thr, mean, u[M - 1], v[M - 1], x[M - 1], y[M - 1], z[M - 1], F, R);
+    } else {
+        for (int64_t i = tid; i < M; i += stride) stage2_point(T, cam, thr, mean, u[i], v[i], x[i], y[i], z[i], F, R);
+    }
+    double vals[S2_USED];
+    pack_sets(F, R, vals);
+    const double tot = block_sum<S2_USED, NT>(vals, lds);
+    if (threadIdx.x < S2_USED) row[threadIdx.x] = tot;
+    else if (threadIdx.x < PICP_S2_DOUBLES) row[threadIdx.x] = 0.0;
+}
+
+// Folds partial records into one record in caller memory (the all-reduce payload when sharded).
+template <int NV>
+__global__ __launch_bounds__(NT) void fold_kernel(const double* __restrict__ part, int rows,
+                                                  const double* __restrict__ state, double* __restrict__ out) {
+    __shared__ double lds[NT];
+    if (state != nullptr && state[ST_STOP] != 0.0) return;
+    const double tot = fold_partials<NV, NT>(part, rows, NV, lds);
+    if (threadIdx.x < NV) out[threadIdx.x] = tot;
+}
+
+// ---- solve + schedules -------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void solve_kernel(double* __restrict__ state, picp_schedule sc,
+                                                   const double* __restrict__ s1part, int s1rows,
+                                                   const double* __restrict__ s2part, int s2rows,
+                                                   double* __restrict__ hist, int hist_rows) {
+    __shared__ double lds[NT];
+    __shared__ double s1[PICP_S1_DOUBLES];
+    __shared__ double s2[PICP_S2_DOUBLES];
+    if (state[ST_STOP] != 0.0) return;
+    {
+        const double t1 = fold_partials<PICP_S1_DOUBLES, NT>(s1part, s1rows, PICP_S1_DOUBLES, lds);
+        if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = t1;
+        __syncthreads();
+        // stage 2 wrote nothing meaningful when stage 1 kept nothing; do not read it then
+        const bool have2 = (s1[S1_COUNT] != 0.0);
+        const double t2 = have2 ? fold_partials<PICP_S2_DOUBLES, NT>(s2part, s2rows, PICP_S2_DOUBLES, lds) : 0.0;
+        if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = t2;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int it = (int)state[ST_IT];
+        double* row = (hist != nullptr && it < hist_rows) ? hist + (size_t)it * PICP_HIST_STRIDE : nullptr;
+        solve_and_schedule(state, s1, s2, sc, row);
+    }
+}
+
+// ---- whole loop in one workgroup, one problem per workgroup -------------------------------------
+// R > 0: each thread keeps up to R correspondences in registers for the whole loop, so the data
+// is read from HBM once per problem.  R == 0: any size, re-read (from cache) every iteration.
+template <int R>
+__global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restrict__ u, const double* __restrict__ v,
+                                                         const double* __restrict__ x, const double* __restrict__ y,
+                                                         const double* __restrict__ z,
+                                                         const int64_t* __restrict__ offsets,
+                                                         const double* __restrict__ poses0, CameraK cam,
+                                                         picp_schedule sc, picp_result* __restrict__ results,
+                                                         double* __restrict__ hist, int hist_rows) {
+    __shared__ double st[PICP_STATE_DOUBLES];
+    __shared__ double lds[(NT / 64) * S2_USED > NT ? (NT / 64) * S2_USED : NT];
+    __shared__ double s1[PICP_S1_DOUBLES];
+    __shared__ double s2[PICP_S2_DOUBLES];
+    const int prob = blockIdx.x;
+    const int64_t beg = offsets[prob];
+    const int cnt = (int)(offsets[prob + 1] - beg);
+    if (threadIdx.x == 0) init_state(st, poses0 + (size_t)prob * 16, sc.kernel_threshold, sc.damping, sc.num_iterations);
+    constexpr int RR = (R > 0) ? R : 1;
+    double ru[RR], rv[RR], rx[RR], ry[RR], rz[RR];
+    if (R > 0) {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const int i = r * NT + threadIdx.x;
+            const bool ok = i < cnt;
+            ru[r] = ok ? u[beg + i] : 0.0;
+            rv[r] = ok ? v[beg + i] : 0.0;
+            rx[r] = ok ? x[beg + i] : 0.0;
+            ry[r] = ok ? y[beg + i] : 0.0;
+            rz[r] = ok ? z[beg + i] : 0.0;
+        }
+    }
+    __syncthreads();
+    double* myhist = (hist != nullptr) ? hist + (size_t)prob * hist_rows * PICP_HIST_STRIDE : nullptr;
+    while (st[ST_STOP] == 0.0) {
+        double T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = st[ST_C_T_W + i];
+        const double thr = st[ST_THR];
+        Stage1Sums a{0.0, 0u, 0u};
+        if (R > 0) {
+#pragma unroll
+            for (int r = 0; r < RR; ++r)
+                if (r * NT + (int)threadIdx.x < cnt) stage1_point(T, cam, thr, ru[r], rv[r], rx[r], ry[r], rz[r], a);
+        } else {
+            for (int i = threadIdx.x; i < cnt; i += NT)
+                stage1_point(T, cam, thr, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], a);
+        }
+        {
+            const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
+            const double tot = block_sum<3, NT>(vals, lds);
+            if (threadIdx.x < 3) s1[threadIdx.x] = tot;
+            __syncthreads();
+        }
+        const double n1 = s1[S1_COUNT];
+        if (n1 != 0.0) {
+            const double mean = s1[S1_SUM_CHI] / n1;
+            SetSums F, Rs;
+            F.clear();
+            Rs.clear();
+            if (R > 0) {
+#pragma unroll
+                for (int r = 0; r < RR; ++r)
+                    if (r * NT + (int)threadIdx.x < cnt)
+                        stage2_point(T, cam, thr, mean, ru[r], rv[r], rx[r], ry[r], rz[r], F, Rs);
+            } else {
+                for (int i = threadIdx.x; i < cnt; i += NT)
+                    stage2_point(T, cam, thr, mean, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], F, Rs);
+            }
+            double vals[S2_USED];
+            pack_sets(F, Rs, vals);
+            const double tot = block_sum<S2_USED, NT>(vals, lds);
+            if (threadIdx.x < S2_USED) s2[threadIdx.x] = tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const int it = (int)st[ST_IT];
+            double* row = (myhist != nullptr && it < hist_rows) ? myhist + (size_t)it * PICP_HIST_STRIDE : nullptr;
+            solve_and_schedule(st, s1, s2, sc, row);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        picp_result r;
+        const bool valid = (st[ST_IT] > 0.0) && !(st[ST_BEST_ERR] > 5.0); // src/ProjectiveICP.py:249
+        for (int i = 0; i < 16; ++i) r.T[i] = valid ? st[ST_BEST_T + i] : st[ST_START_T + i];
+        r.valid = valid ? 1 : 0;
+        r.num_iterations = (int)st[ST_IT];
+        r.best_index = (int)st[ST_BEST_IT];
+        r.reserved = 0;
+        r.best_error = st[ST_BEST_ERR];
+        results[prob] = r;
+    }
+}
+
+__global__ void invert_kernel(const double* in, double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) invert4x4(in, out);
+}
+__global__ void v2T_kernel(const double* in, double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) v2T_device(in, out);
+}
+
+// ---- host helpers ------------------------------------------------------------------------------
+static CameraK to_device_camera(const picp_camera* cam) {
+    CameraK c;
+    for (int i = 0; i < 9; ++i) c.k[i] = cam->K[i];
+    c.width = cam->width;
+    c.height = cam->height;
+    return c;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int grid_for(const picp_ctx* ctx, int64_t M, int per_thread) {
+    const int64_t want = (M + (int64_t)NT * per_thread - 1) / ((int64_t)NT * per_thread);
+    int64_t g = want < 1 ? 1 : want;
+    if (g > ctx->max_blocks) g = ctx->max_blocks;
+    return (int)g;
+}
+
+static int check_corr(const double* u, const double* v, const double* x, const double* y, const double* z, int64_t M) {
+    PICP_REQUIRE(M >= 0, "negative correspondence count %lld", (long long)M);
+    PICP_REQUIRE(M == 0 || (u && v && x && y && z), "null correspondence array with M = %lld", (long long)M);
+    return PICP_OK;
+}
+
+static int check_pose(const double* T) {
+    PICP_REQUIRE(T != nullptr, "null pose");
+    PICP_REQUIRE(T[12] == 0.0 && T[13] == 0.0 && T[14] == 0.0 && T[15] == 1.0,
+                 "pose last row must be (0,0,0,1), got (%g,%g,%g,%g)", T[12], T[13], T[14], T[15]);
+    return PICP_OK;
+}
+
+} // namespace picp
+
+using namespace picp;
+
+extern "C" {
+
+int picp_state_init(picp_ctx* ctx, double* state, const double* w_T_c0_host, const picp_schedule* sched) {
+    PICP_REQUIRE(ctx && state && sched, "picp_state_init: null argument");
+    if (int rc = check_pose(w_T_c0_host)) return rc;
+    DeviceGuard g(ctx->device);
+    Pose16 p;
+    memcpy(p.m, w_T_c0_host, sizeof(p.m));
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, ctx->stream, state, p, sched->kernel_threshold,
+                       sched->damping, sched->num_iterations);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+int picp_stage1(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
+                int64_t M, const double* state, const picp_camera* cam) {
+    PICP_REQUIRE(ctx && state && cam, "picp_stage1: null argument");
+    if (int rc = check_corr(u, v, x, y, z, M)) return rc;
+    DeviceGuard g(ctx->device);
+    const CameraK c = to_device_camera(cam);
+    const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
+    const int grid = grid_for(ctx, vec ? (M + 1) / 2 : M, 1);
+    ctx->rows1 = grid;
+    if (vec)
+        hipLaunchKernelGGL(stage1_kernel<2>, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, ctx->part1);
+    else
+        hipLaunchKernelGGL(stage1_kernel<1>, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, ctx->part1);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+int picp_stage1_reduce(picp_ctx* ctx, double* s1) {
+    PICP_REQUIRE(ctx && s1, "picp_stage1_reduce: null argument");
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(fold_kernel<PICP_S1_DOUBLES>, dim3(1), dim3(NT), 0, ctx->stream, ctx->part1, ctx->rows1,
+                       (const double*)nullptr, s1);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
+                int64_t M, const double* state, const picp_camera* cam, const double* s1) {
+    PICP_REQUIRE(ctx && state && cam, "picp_stage2: null argument");
+    if (int rc = check_corr(u, v, x, y, z, M)) return rc;
+    DeviceGuard g(ctx->device);
+    const CameraK c = to_device_camera(cam);
+    const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
+    const int grid = grid_for(ctx, vec ? (M + 1) / 2 : M, 1);
+    ctx->rows2 = grid;
+    const double* s1p = s1 ? s1 : ctx->part1;
+    const int s1rows = s1 ? 1 : ctx->rows1;
+    if (vec)
+        hipLaunchKernelGGL(stage2_kernel<2>, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p,
+                           s1rows, ctx->part2);
+    else
+        hipLaunchKernelGGL(stage2_kernel<1>, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p,
+                           s1rows, ctx->part2);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+int picp_stage2_reduce(picp_ctx* ctx, double* s2) {
+    PICP_REQUIRE(ctx && s2, "picp_stage2_reduce: null argument");
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(fold_kernel<PICP_S2_DOUBLES>, dim3(1), dim3(NT), 0, ctx->stream, ctx->part2, ctx->rows2,
+                       (const double*)nullptr, s2);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+int picp_solve(picp_ctx* ctx, double* state, const picp_schedule* sched, const double* s1, const double* s2,
+               double* hist, int32_t hist_rows) {
+    PICP_REQUIRE(ctx && state && sched, "picp_solve: null argument");
+    PICP_REQUIRE(hist == nullptr || hist_rows >= 0, "picp_solve: negative hist_rows");
+    DeviceGuard g(ctx->device);
+    const double* s1p = s1 ? s1 : ctx->part1;
+    const int s1rows = s1 ? 1 : ctx->rows1;
+    const double* s2p = s2 ? s2 : ctx->part2;
+    const int s2rows = s2 ? 1 : ctx->rows2;
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(NT), 0, ctx->stream, state, *sched, s1p, s1rows, s2p, s2rows, hist,
+                       (int)hist_rows);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+int picp_finish(picp_ctx* ctx, const double* state, const double* hist, int32_t hist_rows,
+                const double* w_T_c0_host, picp_result* result) {
+    (void)hist;
+    (void)hist_rows;
+    PICP_REQUIRE(ctx && state && result, "picp_finish: null argument");
+    DeviceGuard g(ctx->device);
+    double* h = ctx->pinned;
+    PICP_HIP_CHECK(hipMemcpyAsync(h, state, PICP_STATE_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int n_it = (int)h[ST_IT];
+    // src/ProjectiveICP.py:249-257: invalid when the smallest error is > 5 (NaN-free by construction)
+    const bool valid = n_it > 0 && !(h[ST_BEST_ERR] > 5.0);
+    for (int i = 0; i < 16; ++i) result->T[i] = valid ? h[ST_BEST_T + i] : (w_T_c0_host ? w_T_c0_host[i] : h[ST_START_T + i]);
+    result->valid = valid ? 1 : 0;
+    result->num_iterations = n_it;
+    result->best_index = (int)h[ST_BEST_IT];
+    result->reserved = 0;
+    result->best_error = h[ST_BEST_ERR];
+    return PICP_OK;
+}
+
+int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
+             int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched, double* state,
+             double* hist, int32_t hist_rows, picp_result* result) {
+    PICP_REQUIRE(ctx && cam && sched && state && result, "picp_run: null argument");
+    PICP_REQUIRE(sched->num_iterations >= 0, "picp_run: negative num_iterations");
+    PICP_REQUIRE(hist == nullptr || hist_rows >= sched->num_iterations,
+                 "picp_run: history has %d rows, num_iterations is %d", hist_rows, sched->num_iterations);
+    if (int rc = picp_state_init(ctx, state, w_T_c0_host, sched)) return rc;
+    DeviceGuard g(ctx->device);
+    // Iterations are enqueued in chunks; between chunks the stop flag is read back so that a loop
+    // that converged after a few iterations does not pay for launches that would do nothing.
+    // Every kernel also returns at once when the flag is set, so a chunk may overshoot safely.
+    const int total = sched->num_iterations;
+    int chunk = sched->disable_stop ? total : 8;
+    int issued = 0;
+    while (issued < total) {
+        const int n = (total - issued < chunk) ? (total - issued) : chunk;
+        for (int k = 0; k < n; ++k) {
+            if (int rc = picp_stage1(ctx, u, v, x, y, z, M, state, cam)) return rc;
+            if (int rc = picp_stage2(ctx, u, v, x, y, z, M, state, cam, nullptr)) return rc;
+            if (int rc = picp_solve(ctx, state, sched, nullptr, nullptr, hist, hist_rows)) return rc;
+        }
+        issued += n;
+        if (issued < total) {
+            double* h = ctx->pinned;
+            PICP_HIP_CHECK(hipMemcpyAsync(h, state + ST_STOP, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (h[0] != 0.0) break;
+            if (chunk < 64) chunk *= 2;
+        }
+    }
+    return picp_finish(ctx, state, hist, hist_rows, w_T_c0_host, result);
+}
+
+int picp_run_batched(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                     const double* z, const int64_t* offsets, int32_t B, const double* poses0,
+                     const picp_camera* cam, const picp_schedule* sched, picp_result* results, double* hist,
+                     int32_t hist_rows) {
+    PICP_REQUIRE(ctx && offsets && poses0 && cam && sched && results, "picp_run_batched: null argument");
+    PICP_REQUIRE(B >= 0, "picp_run_batched: negative batch");
+    PICP_REQUIRE(hist == nullptr || hist_rows >= sched->num_iterations,
+                 "picp_run_batched: history has %d rows, num_iterations is %d", hist_rows, sched->num_iterations);
+    if (B == 0) return PICP_OK;
+    DeviceGuard g(ctx->device);
+    const CameraK c = to_device_camera(cam);
+    hipLaunchKernelGGL(icp_batched_kernel<0>, dim3(B), dim3(NT), 0, ctx->stream, u, v, x, y, z, offsets, poses0, c,
+                       *sched, results, hist, (int)hist_rows);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+int picp_linearize(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                   const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
+                   double kernel_threshold, int32_t min_inliers, double* H, double* b, int64_t* num_inliers,
+                   double* error, int64_t* n_inside) {
+    PICP_REQUIRE(ctx && cam && H && b && num_inliers && error, "picp_linearize: null argument");
+    picp_schedule sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.num_iterations = 1;
+    sc.min_inliers = min_inliers;
+    sc.kernel_threshold = kernel_threshold;
+    sc.damping = 1.0;
+    double* state = ctx->scratch + SCR_STATE;
+    double* s1 = ctx->scratch + SCR_S1;
+    double* s2 = ctx->scratch + SCR_S2;
+    if (int rc = picp_state_init(ctx, state, w_T_c0_host, &sc)) return rc;
+    DeviceGuard g(ctx->device);
+    PICP_HIP_CHECK(hipMemsetAsync(s2, 0, PICP_S2_DOUBLES * sizeof(double), ctx->stream));
+    if (int rc = picp_stage1(ctx, u, v, x, y, z, M, state, cam)) return rc;
+    if (int rc = picp_stage1_reduce(ctx, s1)) return rc;
+    if (int rc = picp_stage2(ctx, u, v, x, y, z, M, state, cam, s1)) return rc;
+    if (int rc = picp_stage2_reduce(ctx, s2)) return rc;
+    double* h = ctx->pinned;
+    PICP_HIP_CHECK(hipMemcpyAsync(h, s1, (SCR_S2 - SCR_S1 + PICP_S2_DOUBLES) * sizeof(double), hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const double* hs1 = h;
+    const double* hs2 = h + (SCR_S2 - SCR_S1);
+    for (int i = 0; i < 36; ++i) H[i] = 0.0;
+    for (int i = 0; i < 6; ++i) b[i] = 0.0;
+    if (n_inside) *n_inside = (int64_t)hs1[S1_N_INSIDE];
+    if (hs1[S1_COUNT] == 0.0) { // src/ProjectiveICP.py:300
+        *num_inliers = 0;
+        *error = __builtin_inf();
+        return PICP_OK;
+    }
+    const bool use_f = hs2[S2_N_F] >= (double)min_inliers; // :307
+    int k = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j, ++k) {
+            const double hv = use_f ? hs2[S2_HF + k] : hs2[S2_HF + k] + hs2[S2_HR + k];
+            H[i * 6 + j] = hv;
+            H[j * 6 + i] = hv;
+        }
+    for (int i = 0; i < 6; ++i) b[i] = use_f ? hs2[S2_BF + i] : hs2[S2_BF + i] + hs2[S2_BR + i];
+    const double n = use_f ? hs2[S2_N_F] : hs2[S2_N_F] + hs2[S2_N_R];
+    const double chi = use_f ? hs2[S2_CHI_F] : hs2[S2_CHI_F] + hs2[S2_CHI_R];
+    *num_inliers = (int64_t)n;
+    *error = n > 0.0 ? chi / n : __builtin_inf();
+    return PICP_OK;
+}
+
+int picp_invert_pose(picp_ctx* ctx, const double* T_host, double* Tinv_host) {
+    PICP_REQUIRE(ctx && T_host && Tinv_host, "picp_invert_pose: null argument");
+    DeviceGuard g(ctx->device);
+    double* d = ctx->scratch + SCR_MISC;
+    PICP_HIP_CHECK(hipMemcpyAsync(d, T_host, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)d, d + 16);
+    PICP_HIP_CHECK(hipGetLastError());
+    PICP_HIP_CHECK(hipMemcpyAsync(Tinv_host, d + 16, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PICP_OK;
+}
+
+int picp_v2T(picp_ctx* ctx, const double* v6_host, double* T_host) {
+    PICP_REQUIRE(ctx && v6_host && T_host, "picp_v2T: null argument");
+    DeviceGuard g(ctx->device);
+    double* d = ctx->scratch + SCR_MISC;
+    PICP_HIP_CHECK(hipMemcpyAsync(d, v6_host, 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(v2T_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)d, d + 16);
+    PICP_HIP_CHECK(hipGetLastError());
+    PICP_HIP_CHECK(hipMemcpyAsync(T_host, d + 16, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PICP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,268 @@
+"""HIP path against the reference-generated golden vectors and the CPU oracle, through the C ABI.
+
+Bars (north star): association indices, in-image counts, inlier counts, iteration counts, schedules
+bit-exact; H, b, poses within 1e-9 relative (b relative to the magnitude of its terms, see
+conftest.b_err).
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from tests.helpers import b_err, load_golden, rel_err
+from oracle import picp_oracle as po
+from tests.synthetic import make_problem
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+pkg = importlib.import_module("monocular-visual-odometry_amd")
+L = pkg._lib
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return pkg.get_context(0)
+
+
+def yaml_sched(num_iterations=250, disable_stop=False, **over):
+    p = dict(min_inliers=10, kernel_threshold=1000, min_kernel_threshold=10, max_kernel_threshold=2000,
+             damping=64, min_damping=1, max_damping=64)
+    p.update(over)
+    return L.schedule_struct(num_iterations, p["min_inliers"], p["kernel_threshold"], p["min_kernel_threshold"],
+                             p["max_kernel_threshold"], p["damping"], p["min_damping"], p["max_damping"], disable_stop)
+
+
+def bundled_cam():
+    return L.camera_struct([[180, 0, 320], [0, 180, 240], [0, 0, 1]], 640, 480)
+
+
+def check_history(hist, g, pre, lo=None, hi=None):
+    """Device history rows against the reference's per-iteration records."""
+    sl = slice(lo, hi)
+    e_ref = g[f"{pre}error"][sl]
+    assert hist.shape[0] == len(e_ref)
+    assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), g[f"{pre}num_inliers"][sl])
+    assert np.array_equal(hist[:, L.H_N_INSIDE].astype(np.int64), g[f"{pre}n_inside"][sl])
+    assert np.array_equal(hist[:, L.H_KERNEL_THR], g[f"{pre}kernel_threshold"][sl])
+    assert np.array_equal(hist[:, L.H_DAMPING], g[f"{pre}dumping_factor"][sl])
+    e = hist[:, L.H_ERROR]
+    assert np.array_equal(np.isinf(e), np.isinf(e_ref))
+    fin = np.isfinite(e_ref)
+    assert np.all(np.abs(e[fin] - e_ref[fin]) <= 1e-8 * np.abs(e_ref[fin]) + 1e-18)
+    assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), g[f"{pre}T"][sl]) < TOL
+    Href, bref, dxref = g[f"{pre}H"][sl], g[f"{pre}b"][sl], g[f"{pre}dx"][sl]
+    for k in range(hist.shape[0]):
+        H = hist[k, L.H_H:L.H_H + 36].reshape(6, 6)
+        if np.max(np.abs(Href[k])) > 0:
+            assert rel_err(H, Href[k]) < TOL, k
+        assert b_err(hist[k, L.H_B:L.H_B + 6], bref[k], Href[k], g[f"{pre}num_inliers"][sl][k], e_ref[k]) < TOL, k
+        if np.max(np.abs(dxref[k])) > 0:
+            assert np.max(np.abs(hist[k, L.H_DX:L.H_DX + 6] - dxref[k])) <= 1e-8 * np.max(np.abs(dxref[k])) + 1e-15, k
+
+
+def test_device_v2T_float32_trig(ctx):
+    g = load_golden("ref_v2T.npz")
+    for v, T in zip(g["v"], g["T"]):
+        Td = ctx.v2T(v)
+        if np.max(np.abs(v[3:])) <= 1e-2:
+            # the magnitudes the loop produces: identical float32 sines/cosines; the two 3x3 products
+            # may round differently from numpy's BLAS in the last bit
+            assert np.max(np.abs(Td - T)) <= 4.5e-16, v
+        else:
+            assert np.max(np.abs(Td - T)) < 2.5e-7, v  # numpy's float32 sin/cos is within 1.5 ulp, not exact
+
+
+def test_device_pose_inverse(ctx):
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        T = po.v2T(rng.uniform(-1, 1, 6) * np.array([5, 5, 5, 3, 3, 3]))
+        assert rel_err(ctx.invert_pose(T), np.linalg.inv(T)) < 1e-14
+
+
+def test_linearize_reference_cases(ctx):
+    g = load_golden("ref_synthetic.npz")
+    cam = bundled_cam()
+    for ci in range(int(g["n_cases"])):
+        uv, pw, thr, pose = g[f"c{ci}_uv"], g[f"c{ci}_pw"], float(g[f"c{ci}_thr"]), g[f"c{ci}_pose"]
+        H, b, n, err, n_in = ctx.linearize(ctx.soa(uv, pw), pose, cam, thr, 10)
+        assert n == int(g[f"c{ci}_n"]), ci
+        assert rel_err(H, g[f"c{ci}_H"]) < TOL or np.max(np.abs(g[f"c{ci}_H"])) == 0, ci
+        assert b_err(b, g[f"c{ci}_b"], g[f"c{ci}_H"], n, g[f"c{ci}_err"]) < TOL, ci
+        if np.isinf(g[f"c{ci}_err"]):
+            assert np.isinf(err)
+        else:
+            assert abs(err - g[f"c{ci}_err"]) <= TOL * abs(g[f"c{ci}_err"])
+
+
+def test_linearize_edge_cases(ctx):
+    g = load_golden("ref_synthetic.npz")
+    cam = bundled_cam()
+    corr = ctx.soa(g["edge_uv"], g["edge_pw"])
+    for ti in range(int(g["n_edge"])):
+        H, b, n, err, _ = ctx.linearize(corr, np.eye(4), cam, float(g[f"edge{ti}_thr"]), 10)
+        assert n == int(g[f"edge{ti}_n"])
+        assert rel_err(H, g[f"edge{ti}_H"]) < TOL
+        assert b_err(b, g[f"edge{ti}_b"], g[f"edge{ti}_H"], n, g[f"edge{ti}_err"]) < TOL
+        assert abs(err - g[f"edge{ti}_err"]) <= TOL * abs(g[f"edge{ti}_err"])
+
+
+@pytest.mark.parametrize("path", ["kernels", "workgroup"])
+def test_full_loop_reference_synthetic(ctx, path):
+    g = load_golden("ref_synthetic.npz")
+    cam = bundled_cam()
+    for li in range(int(g["n_loops"])):
+        pre = f"loop{li}_"
+        sched = yaml_sched(int(g[f"{pre}num_iterations"]))
+        corr = ctx.soa(g[f"{pre}uv"], g[f"{pre}pw"])
+        if path == "kernels":
+            res, hist = ctx.run(corr, g[f"{pre}pose"], cam, sched)
+            T, valid = np.array(list(res.T)).reshape(4, 4), bool(res.valid)
+        else:
+            M = len(g[f"{pre}uv"])
+            results, h = ctx.run_batched(corr, ctx.to_device(np.array([0, M]), np.int64),
+                                         ctx.to_device(g[f"{pre}pose"].reshape(1, 16)), cam, sched, want_history=True)
+            r = ctx.decode_results(results.cpu().numpy())
+            hist = h[0, : r["num_iterations"][0]].cpu().numpy()
+            T, valid = r["T"][0], bool(r["valid"][0])
+        check_history(hist, g, pre)
+        assert valid == bool(g[f"{pre}valid"])
+        assert rel_err(T, g[f"{pre}T_out"]) < TOL
+
+
+def _gtmap_problems(bundled, g):
+    mo = bundled["meas_offsets"]
+    uvs, pws = [], []
+    for f in range(120):
+        uv = bundled["meas_uv"][mo[f + 1]:mo[f + 2]]
+        act = bundled["meas_actual_id"][mo[f + 1]:mo[f + 2]]
+        uvs.append(uv)
+        pws.append(g["map_position"][act])
+    return uvs, pws
+
+
+def test_gtmap_icp_120_frames_kernel_path(ctx, bundled):
+    """The reference loop's 1 574 iterations on the bundled measurements (ground-truth map), launched
+    as stage-1 / stage-2 / solve kernels per iteration."""
+    g = load_golden("ref_gtmap_icp.npz")
+    cam, sched = bundled_cam(), yaml_sched()
+    offs = g["iter_offsets"]
+    uvs, pws = _gtmap_problems(bundled, g)
+    for f in range(0, 120, 7):          # every 7th frame (the batched test below covers all 120)
+        res, hist = ctx.run(ctx.soa(uvs[f], pws[f]), g["start_pose"][f], cam, sched)
+        check_history(hist, g, "", offs[f], offs[f + 1])
+        assert bool(res.valid) == bool(g["valid"][f])
+        assert rel_err(np.array(list(res.T)).reshape(4, 4), g["T_out"][f]) < TOL
+
+
+def test_gtmap_icp_120_frames_batched(ctx, bundled):
+    """All 120 frame problems in ONE launch, one workgroup per frame, whole loop inside the kernel."""
+    g = load_golden("ref_gtmap_icp.npz")
+    cam, sched = bundled_cam(), yaml_sched()
+    offs = g["iter_offsets"]
+    uvs, pws = _gtmap_problems(bundled, g)
+    counts = np.array([len(u) for u in uvs])
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    corr = ctx.soa(np.concatenate(uvs), np.concatenate(pws))
+    results, hist = ctx.run_batched(corr, ctx.to_device(offsets, np.int64),
+                                    ctx.to_device(g["start_pose"].reshape(120, 16)), cam, sched, want_history=True)
+    r = ctx.decode_results(results.cpu().numpy())
+    hist = hist.cpu().numpy()
+    for f in range(120):
+        n_it = int(r["num_iterations"][f])
+        check_history(hist[f, :n_it], g, "", offs[f], offs[f + 1])
+        assert bool(r["valid"][f]) == bool(g["valid"][f])
+        assert rel_err(r["T"][f], g["T_out"][f]) < TOL
+        assert int(r["best_index"][f]) == int(np.argmin(g["error"][offs[f]:offs[f + 1]]))
+
+
+def test_association_reference_cases(ctx):
+    g = load_golden("ref_association.npz")
+    i1, i2 = ctx.associate(ctx.to_device(g["app1"]), ctx.to_device(g["app2"]))
+    r1, r2 = po.associate(g["app1"], g["app2"])
+    assert np.array_equal(i1.cpu().numpy(), r1) and np.array_equal(i2.cpu().numpy(), r2)
+    s1 = {"position": g["pos1"].tolist(), "appearance": g["app1"].tolist()}
+    s2 = {"position": g["pos2"].tolist(), "appearance": g["app2"].tolist()}
+    m0 = pkg.data_association_on_appearance(s1, s2)
+    assert np.array_equal(np.array(m0["points_1"]), g["m0_p1"])
+    assert np.array_equal(np.array(m0["points_2"]), g["m0_p2"])
+    assert np.array_equal(np.array(m0["appearance"]), g["m0_app"], equal_nan=True)
+    cam = pkg.Camera.Camera(camera_matrix=[[180, 0, 320], [0, 180, 240], [0, 0, 1]], camera_resolution=[640, 480])
+    cam.set_c_T_w(g["c_T_w"])
+    m2 = pkg.data_association_on_appearance(s1, s2, projection=2, camera=cam)
+    assert list(m2.keys()) == ["points_1", "points_2", "projected_points_2", "appearance"]
+    assert np.array_equal(np.array(m2["points_1"]), g["m2_p1"])
+    assert np.array_equal(np.array(m2["points_2"]), g["m2_p2"])
+    assert rel_err(np.array(m2["projected_points_2"]), g["m2_proj"]) < 1e-13
+    s1b = {"position": g["pos2"][: len(g["app1"])].tolist(), "appearance": g["app1"].tolist()}
+    m1 = pkg.data_association_on_appearance(s1b, s2, projection=1, camera=cam)
+    assert list(m1.keys()) == ["points_1", "projected_points_1", "points_2", "appearance"]
+    assert np.array_equal(np.array(m1["points_1"]), g["m1_p1"])
+    assert np.array_equal(np.array(m1["points_2"]), g["m1_p2"])
+    assert rel_err(np.array(m1["projected_points_1"]), g["m1_proj"]) < 1e-13
+
+
+def test_association_sizes_and_duplicates(ctx):
+    rng = np.random.default_rng(11)
+    for n1, n2, D in [(1, 1, 10), (3, 5000, 10), (5000, 3, 10), (4097, 4099, 10), (2000, 3000, 3), (300, 300, 1),
+                      (70000, 9000, 10)]:
+        app2 = rng.integers(-3, 4, (n2, D)).astype(np.float64) if D <= 3 else rng.uniform(-1, 1, (n2, D))
+        app1 = app2[rng.integers(0, n2, n1)].copy()
+        app1[::7] = rng.uniform(-1, 1, (len(app1[::7]), D))
+        i1, i2 = ctx.associate(ctx.to_device(app1), ctx.to_device(app2))
+        r1, r2 = po.associate(app1, app2)
+        assert np.array_equal(i1.cpu().numpy(), r1), (n1, n2, D)
+        assert np.array_equal(i2.cpu().numpy(), r2), (n1, n2, D)
+    e1, e2 = ctx.associate(ctx.to_device(np.zeros((0, 10))), ctx.to_device(np.zeros((5, 10))))
+    assert e1.numel() == 0 and e2.numel() == 0
+
+
+def test_large_loop_against_oracle(ctx):
+    """2^20 correspondences, 6 iterations: counts exact, H/b/T within 1e-9 of the numpy oracle."""
+    M = 1 << 20
+    uv, pw, _ = make_problem(M, seed=0)
+    params = po.IcpParams(num_iterations=6, disable_stop=True)
+    T_ref, valid_ref, h_ref = po.projective_icp(uv, pw, np.eye(4), params, record_linear=True)
+    res, hist = ctx.run(ctx.soa(uv, pw), np.eye(4), bundled_cam(), yaml_sched(6, disable_stop=True))
+    assert res.num_iterations == 6
+    assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h_ref["num_inliers"]))
+    assert np.array_equal(hist[:, L.H_N_INSIDE].astype(np.int64), np.array(h_ref["n_inside"]))
+    assert np.array_equal(hist[:, L.H_KERNEL_THR], np.array(h_ref["kernel_threshold"], dtype=np.float64))
+    for k in range(6):
+        assert rel_err(hist[k, L.H_H:L.H_H + 36].reshape(6, 6), h_ref["H"][k]) < TOL
+        assert b_err(hist[k, L.H_B:L.H_B + 6], h_ref["b"][k], h_ref["H"][k], h_ref["num_inliers"][k], h_ref["error"][k]) < TOL
+        assert rel_err(hist[k, L.H_T:L.H_T + 16].reshape(4, 4), h_ref["T"][k]) < TOL
+    assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
+    # unaligned / odd-length views take the scalar-load kernels: same answer
+    corr = ctx.soa(uv, pw)
+    odd = [c[1:M - 2] for c in corr]
+    res2, hist2 = ctx.run(odd, np.eye(4), bundled_cam(), yaml_sched(2, disable_stop=True))
+    T2, _, h2 = po.projective_icp(uv[1:M - 2], pw[1:M - 2], np.eye(4), po.IcpParams(num_iterations=2, disable_stop=True))
+    assert np.array_equal(hist2[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h2["num_inliers"]))
+    assert rel_err(np.array(list(res2.T)).reshape(4, 4), T2) < TOL
+
+
+def test_projective_icp_class_on_bundled_frames(ctx, bundled, tmp_path, monkeypatch):
+    """The drop-in class: same call sequence a reference-style driver makes, ground-truth map injected."""
+    from tests.bundled import write_data_dir
+    write_data_dir(str(tmp_path / "data"))
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("ref_gtmap_icp.npz")
+    cam, data = pkg.Camera.Camera(), pkg.Data.Data()
+    picp = pkg.ProjectiveICP.ProjectiveICP(cam, data, 250, 10, 1000, 10, 2000, 64, 1, 64, False, False, False, [])
+    m = picp.get_map()
+    m["position"] = [p for p in g["map_position"]]
+    m["appearance"] = [list(a) for a in g["map_appearance"]]
+    m["error"] = [0.0] * len(m["position"])
+    offs = g["iter_offsets"]
+    for f in (0, 17, 52, 75, 119):
+        picp._ProjectiveICP__current_pose = g["start_pose"][f]
+        cam.set_c_T_w(np.linalg.inv(g["start_pose"][f]))
+        T, valid, res = picp.projective_icp(data.get_measurements_data(f + 1), f)
+        assert valid == bool(g["valid"][f])
+        assert len(res["T"]) == offs[f + 1] - offs[f]
+        assert res["num_inliers"] == g["num_inliers"][offs[f]:offs[f + 1]].tolist()
+        assert res["kernel_threshold"] == g["kernel_threshold"][offs[f]:offs[f + 1]].tolist()
+        assert res["dumping_factor"] == g["dumping_factor"][offs[f]:offs[f + 1]].tolist()
+        assert rel_err(T, g["T_out"][f]) < TOL
+        assert rel_err(cam.get_c_T_w(), np.linalg.inv(g["T_out"][f])) < TOL

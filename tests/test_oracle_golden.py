@@ -7,11 +7,11 @@ counts, best index, validity) identical; float results within 1e-9 norm-relative
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+from tests.helpers import load_golden, rel_err
 from oracle import picp_oracle as po
 
 TOL = 1e-9
-from conftest import b_err
+from tests.helpers import b_err
 
 
 def test_v2T_matches_reference_float32_trig():
