@@ -188,27 +188,40 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
     return out;
 }
 
-// Folds `rows` partial records of NV doubles (row stride `stride`) into totals, rows added in
-// index order per column group so the result does not depend on scheduling.  Every thread with
-// tid < NV of a workgroup of NT threads returns the total of column tid.
+// Folds `rows` partial records of NV doubles (row stride `stride`) into totals.  Every thread with
+// tid < NV of a workgroup of NT threads returns the total of column tid.  The workgroup is split
+// into NT/CW row groups of CW lanes (CW = NV rounded up to a power of two); a group adds its rows in
+// index order, then the groups are added in index order, so the result does not depend on
+// scheduling.  Loads are issued in independent batches of B: a one-load-per-iteration loop would
+// pay a full memory round trip per row.
 // lds: at least NT doubles.
-template <int NV, int NT>
+template <int NV, int NT, int B = 16>
 __device__ __forceinline__ double fold_partials(const double* __restrict__ part, int rows, int stride,
                                                 double* lds) {
-    static_assert(NV <= 64 && NT % 64 == 0, "column per lane");
-    constexpr int G = NT / 64; // row groups
-    const int col = threadIdx.x & 63;
-    const int grp = threadIdx.x >> 6;
+    constexpr int CW = NV <= 4 ? 4 : (NV <= 8 ? 8 : (NV <= 16 ? 16 : (NV <= 32 ? 32 : 64)));
+    static_assert(NV <= 64 && NT % CW == 0, "column per lane");
+    constexpr int G = NT / CW; // row groups
+    // B = loads in flight per thread
+    const int col = threadIdx.x % CW;
+    const int grp = threadIdx.x / CW;
     double acc = 0.0;
     if (col < NV) {
-        for (int r = grp; r < rows; r += G) acc += part[(size_t)r * stride + col];
+        for (int r0 = grp; r0 < rows; r0 += G * B) {
+            double v[B];
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const int r = r0 + k * G;
+                v[k] = (r < rows) ? part[(size_t)r * stride + col] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k) acc += v[k];
+        }
     }
     lds[threadIdx.x] = acc;
     __syncthreads();
     double out = 0.0;
     if (threadIdx.x < NV) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) out += lds[g * 64 + threadIdx.x];
+        for (int g = 0; g < G; ++g) out += lds[g * CW + threadIdx.x];
     }
     __syncthreads();
     return out;
@@ -255,9 +268,11 @@ __device__ inline void invert4x4(const double* A, double* Ainv) {
                 }
             }
         }
+        const double pinv = 1.0 / a[k][k];
+        a[k][k] = pinv; // the diagonal holds the pivot reciprocals from here on
 #pragma unroll
         for (int r = k + 1; r < 4; ++r) {
-            const double f = a[r][k] / a[k][k];
+            const double f = a[r][k] * pinv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j > k) a[r][j] -= f * a[k][j];
@@ -273,7 +288,7 @@ __device__ inline void invert4x4(const double* A, double* Ainv) {
             double s = b[i][j];
 #pragma unroll
             for (int k = i + 1; k < 4; ++k) s -= a[i][k] * b[k][j];
-            b[i][j] = s / a[i][i];
+            b[i][j] = s * a[i][i];
         }
     }
 #pragma unroll
@@ -286,18 +301,22 @@ __device__ inline void invert4x4(const double* A, double* Ainv) {
 // The reference calls np.linalg.lstsq (src/ProjectiveICP.py:269-270); the damped matrix is SPD
 // (lambda >= min damping > 0), so the least-squares solution is the unique solution.
 __device__ inline void damped_solve6(const double* H /*36, symmetric*/, const double* b, double lambda, double* dx) {
-    double L[6][6];
+    // Column-oriented Cholesky; Linv[j] = 1 / L[j][j] replaces the divisions by the diagonal (this
+    // runs on a single lane, where each float64 division is a long dependent instruction chain).
+    double L[6][6], Linv[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) {
+        double d = H[j * 6 + j] + lambda;
 #pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            double s = H[i * 6 + j] + ((i == j) ? lambda : 0.0);
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        Linv[j] = rsqrt(d);
+        L[j][j] = d * Linv[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double s = H[i * 6 + j];
 #pragma unroll
             for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-            if (i == j)
-                L[i][i] = sqrt(s);
-            else
-                L[i][j] = s / L[j][j];
+            L[i][j] = s * Linv[j];
         }
     }
     double yv[6];
@@ -306,14 +325,14 @@ __device__ inline void damped_solve6(const double* H /*36, symmetric*/, const do
         double s = -b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= L[i][k] * yv[k];
-        yv[i] = s / L[i][i];
+        yv[i] = s * Linv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = yv[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= L[k][i] * dx[k];
-        dx[i] = s / L[i][i];
+        dx[i] = s * Linv[i];
     }
 }
 

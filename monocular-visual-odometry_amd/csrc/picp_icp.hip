@@ -179,21 +179,23 @@ __global__ __launch_bounds__(NT) void fold_kernel(const double* __restrict__ par
 }
 
 // ---- solve + schedules -------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void solve_kernel(double* __restrict__ state, picp_schedule sc,
+constexpr int NT_SOLVE = 512; // more lanes than the scans: the prologue folds up to max_blocks partial records
+__global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ state, picp_schedule sc,
                                                    const double* __restrict__ s1part, int s1rows,
                                                    const double* __restrict__ s2part, int s2rows,
                                                    double* __restrict__ hist, int hist_rows) {
-    __shared__ double lds[NT];
+    __shared__ double lds[NT_SOLVE];
     __shared__ double s1[PICP_S1_DOUBLES];
     __shared__ double s2[PICP_S2_DOUBLES];
     if (state[ST_STOP] != 0.0) return;
     {
-        const double t1 = fold_partials<PICP_S1_DOUBLES, NT>(s1part, s1rows, PICP_S1_DOUBLES, lds);
+        const double t1 = fold_partials<PICP_S1_DOUBLES, NT_SOLVE>(s1part, s1rows, PICP_S1_DOUBLES, lds);
         if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = t1;
         __syncthreads();
         // stage 2 wrote nothing meaningful when stage 1 kept nothing; do not read it then
         const bool have2 = (s1[S1_COUNT] != 0.0);
-        const double t2 = have2 ? fold_partials<PICP_S2_DOUBLES, NT>(s2part, s2rows, PICP_S2_DOUBLES, lds) : 0.0;
+        const double t2 =
+            have2 ? fold_partials<PICP_S2_DOUBLES, NT_SOLVE, 32>(s2part, s2rows, PICP_S2_DOUBLES, lds) : 0.0;
         if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = t2;
         __syncthreads();
     }
@@ -421,7 +423,7 @@ int picp_solve(picp_ctx* ctx, double* state, const picp_schedule* sched, const d
     const int s1rows = s1 ? 1 : ctx->rows1;
     const double* s2p = s2 ? s2 : ctx->part2;
     const int s2rows = s2 ? 1 : ctx->rows2;
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(NT), 0, ctx->stream, state, *sched, s1p, s1rows, s2p, s2rows, hist,
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(NT_SOLVE), 0, ctx->stream, state, *sched, s1p, s1rows, s2p, s2rows, hist,
                        (int)hist_rows);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;

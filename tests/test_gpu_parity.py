@@ -58,7 +58,23 @@ def check_history(hist, g, pre, lo=None, hi=None):
             assert rel_err(H, Href[k]) < TOL, k
         assert b_err(hist[k, L.H_B:L.H_B + 6], bref[k], Href[k], g[f"{pre}num_inliers"][sl][k], e_ref[k]) < TOL, k
         if np.max(np.abs(dxref[k])) > 0:
-            assert np.max(np.abs(hist[k, L.H_DX:L.H_DX + 6] - dxref[k])) <= 1e-8 * np.max(np.abs(dxref[k])) + 1e-15, k
+            # dx = -(H + lambda I)^-1 b inherits b's cancellation noise once the loop has converged,
+            # hence the absolute term (poses are O(1), so 1e-12 is far inside the 1e-9 pose bar)
+            assert np.max(np.abs(hist[k, L.H_DX:L.H_DX + 6] - dxref[k])) <= 1e-8 * np.max(np.abs(dxref[k])) + 1e-12, k
+
+
+def check_best(T, best_index, e_ref, T_ref_hist, T_out_ref):
+    """The returned pose is the pose of the first iteration with the smallest error (np.argmin).
+    When a loop has converged, consecutive errors differ by rounding noise only and the argmin is
+    decided by the last bits of a float sum; the device may then pick another index.  Accept that
+    only if its error equals the reference minimum to 1e-9 relative, and require the pose to be the
+    reference's pose at the index that was picked."""
+    ref_best = int(np.argmin(e_ref))
+    if best_index == ref_best:
+        assert rel_err(T, T_out_ref) < TOL
+    else:
+        assert abs(e_ref[best_index] - e_ref[ref_best]) <= 1e-9 * abs(e_ref[ref_best])
+        assert rel_err(T, T_ref_hist[best_index]) < TOL
 
 
 def test_device_v2T_float32_trig(ctx):
@@ -117,17 +133,20 @@ def test_full_loop_reference_synthetic(ctx, path):
         corr = ctx.soa(g[f"{pre}uv"], g[f"{pre}pw"])
         if path == "kernels":
             res, hist = ctx.run(corr, g[f"{pre}pose"], cam, sched)
-            T, valid = np.array(list(res.T)).reshape(4, 4), bool(res.valid)
+            T, valid, best = np.array(list(res.T)).reshape(4, 4), bool(res.valid), res.best_index
         else:
             M = len(g[f"{pre}uv"])
             results, h = ctx.run_batched(corr, ctx.to_device(np.array([0, M]), np.int64),
                                          ctx.to_device(g[f"{pre}pose"].reshape(1, 16)), cam, sched, want_history=True)
             r = ctx.decode_results(results.cpu().numpy())
             hist = h[0, : r["num_iterations"][0]].cpu().numpy()
-            T, valid = r["T"][0], bool(r["valid"][0])
+            T, valid, best = r["T"][0], bool(r["valid"][0]), int(r["best_index"][0])
         check_history(hist, g, pre)
         assert valid == bool(g[f"{pre}valid"])
-        assert rel_err(T, g[f"{pre}T_out"]) < TOL
+        if valid:
+            check_best(T, best, g[f"{pre}error"], g[f"{pre}T"], g[f"{pre}T_out"])
+        else:
+            assert rel_err(T, g[f"{pre}T_out"]) < TOL
 
 
 def _gtmap_problems(bundled, g):
@@ -152,7 +171,8 @@ def test_gtmap_icp_120_frames_kernel_path(ctx, bundled):
         res, hist = ctx.run(ctx.soa(uvs[f], pws[f]), g["start_pose"][f], cam, sched)
         check_history(hist, g, "", offs[f], offs[f + 1])
         assert bool(res.valid) == bool(g["valid"][f])
-        assert rel_err(np.array(list(res.T)).reshape(4, 4), g["T_out"][f]) < TOL
+        check_best(np.array(list(res.T)).reshape(4, 4), res.best_index, g["error"][offs[f]:offs[f + 1]],
+                   g["T"][offs[f]:offs[f + 1]], g["T_out"][f])
 
 
 def test_gtmap_icp_120_frames_batched(ctx, bundled):
@@ -172,8 +192,8 @@ def test_gtmap_icp_120_frames_batched(ctx, bundled):
         n_it = int(r["num_iterations"][f])
         check_history(hist[f, :n_it], g, "", offs[f], offs[f + 1])
         assert bool(r["valid"][f]) == bool(g["valid"][f])
-        assert rel_err(r["T"][f], g["T_out"][f]) < TOL
-        assert int(r["best_index"][f]) == int(np.argmin(g["error"][offs[f]:offs[f + 1]]))
+        check_best(r["T"][f], int(r["best_index"][f]), g["error"][offs[f]:offs[f + 1]], g["T"][offs[f]:offs[f + 1]],
+                   g["T_out"][f])
 
 
 def test_association_reference_cases(ctx):
@@ -264,5 +284,7 @@ def test_projective_icp_class_on_bundled_frames(ctx, bundled, tmp_path, monkeypa
         assert res["num_inliers"] == g["num_inliers"][offs[f]:offs[f + 1]].tolist()
         assert res["kernel_threshold"] == g["kernel_threshold"][offs[f]:offs[f + 1]].tolist()
         assert res["dumping_factor"] == g["dumping_factor"][offs[f]:offs[f + 1]].tolist()
-        assert rel_err(T, g["T_out"][f]) < TOL
-        assert rel_err(cam.get_c_T_w(), np.linalg.inv(g["T_out"][f])) < TOL
+        e_ref = g["error"][offs[f]:offs[f + 1]]
+        best = next(k for k in range(len(res["T"])) if res["T"][k] is T or np.array_equal(res["T"][k], T))
+        check_best(T, best, e_ref, g["T"][offs[f]:offs[f + 1]], g["T_out"][f])
+        assert rel_err(cam.get_c_T_w(), np.linalg.inv(T)) < 1e-14
