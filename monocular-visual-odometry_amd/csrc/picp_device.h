@@ -36,18 +36,19 @@ enum : int {
 
 // stage-1 record
 enum : int { S1_SUM_CHI = 0, S1_COUNT = 1, S1_N_INSIDE = 2, S1_PAD = 3 };
-// stage-2 record: two candidate inlier sets, F = {chi < mean} and R = stage-1 survivors not in F.
-// The reference uses F when it has >= min_inliers members, else F u R (:307-310).
+// stage-2 record: sums over two candidate inlier sets,
+//   F = {chi <= threshold and chi < mean}        (the stage-2 set, src/ProjectiveICP.py:302)
+//   A = {chi <= threshold}                       (the stage-1 set, :294)
+// The reference uses F when it has >= min_inliers members, else A (:307-310).  A's chi sum and
+// member count are the stage-1 record's, so only F carries them here.
 enum : int {
     S2_HF = 0,    // [21] upper triangle of sum J^T J over F, row-major (00,01,..,05,11,..,55)
     S2_BF = 21,   // [6]  sum J^T e over F
     S2_CHI_F = 27,
     S2_N_F = 28,
-    S2_HR = 29,   // [21] same over R
-    S2_BR = 50,   // [6]
-    S2_CHI_R = 56,
-    S2_N_R = 57,
-    S2_USED = 58, // number of meaningful entries; the record is padded to PICP_S2_DOUBLES
+    S2_HA = 29,   // [21] same over A
+    S2_BA = 50,   // [6]
+    S2_USED = 56, // number of meaningful entries; the record is padded to PICP_S2_DOUBLES
 };
 
 struct CameraK {
@@ -58,7 +59,22 @@ struct Pose12 { // rows 0..2 of a 4x4 pose, passed to kernels by value
     double m[12];
 };
 
+// True when K = [[fx,0,cx],[0,fy,cy],[0,0,k8]]: the shape of every pinhole camera matrix and of
+// the bundled one (data/camera.dat:2-4).  The kernels then skip the products with the zero
+// entries; since 0*x + y == y for finite x, the results are the same numbers.
+inline bool is_pinhole(const double* K) { return K[1] == 0.0 && K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0; }
+
 __device__ __forceinline__ double d_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+// a / b given r = 1.0 / b (correctly rounded): one multiply and a fused residual correction
+// (q + (a - q b) r).  With a correctly rounded reciprocal this returns the correctly rounded
+// quotient while everything stays far from overflow/underflow; the caller checks that and
+// otherwise divides.
+__device__ __forceinline__ double div_with_recip(double a, double b, double r) {
+    const double q = a * r;
+    const double rem = __builtin_fma(-q, b, a);
+    return __builtin_fma(rem, r, q);
+}
 
 // ---- Camera.project_point (src/Camera.py:104-119) -------------------------------------------
 // T = c_T_w rows 0..2 (12 doubles).  The reference also forms the homogeneous w and divides by
@@ -70,21 +86,38 @@ __device__ __forceinline__ double d_inf() { return __longlong_as_double(0x7ff000
 struct Projected {
     double pcx, pcy, pcz; // point in camera coordinates
     double h0, h1, h2;    // K @ pc
+    double zi;            // 1 / h2
     double u, v;
     bool inside;
 };
 
+template <bool PINHOLE>
 __device__ __forceinline__ Projected project_point(const double* __restrict__ T, const CameraK& cam, double x,
                                                    double y, double z) {
     Projected p;
     p.pcx = T[0] * x + T[1] * y + T[2] * z + T[3];
     p.pcy = T[4] * x + T[5] * y + T[6] * z + T[7];
     p.pcz = T[8] * x + T[9] * y + T[10] * z + T[11];
-    p.h0 = cam.k[0] * p.pcx + cam.k[1] * p.pcy + cam.k[2] * p.pcz;
-    p.h1 = cam.k[3] * p.pcx + cam.k[4] * p.pcy + cam.k[5] * p.pcz;
-    p.h2 = cam.k[6] * p.pcx + cam.k[7] * p.pcy + cam.k[8] * p.pcz;
-    p.u = p.h0 / p.h2;
-    p.v = p.h1 / p.h2;
+    // 0 * inf is NaN: with non-finite coordinates the zero entries of K matter, so those points
+    // take the full products too
+    if (PINHOLE && __builtin_isfinite(p.pcx + p.pcy + p.pcz)) {
+        p.h0 = cam.k[0] * p.pcx + cam.k[2] * p.pcz;
+        p.h1 = cam.k[4] * p.pcy + cam.k[5] * p.pcz;
+        p.h2 = cam.k[8] * p.pcz;
+    } else {
+        p.h0 = cam.k[0] * p.pcx + cam.k[1] * p.pcy + cam.k[2] * p.pcz;
+        p.h1 = cam.k[3] * p.pcx + cam.k[4] * p.pcy + cam.k[5] * p.pcz;
+        p.h2 = cam.k[6] * p.pcx + cam.k[7] * p.pcy + cam.k[8] * p.pcz;
+    }
+    p.zi = 1.0 / p.h2; // also z_inv of the Jacobian (src/ProjectiveICP.py:345)
+    p.u = div_with_recip(p.h0, p.h2, p.zi);
+    p.v = div_with_recip(p.h1, p.h2, p.zi);
+    const double big = 1e150, small = 1e-150;
+    const bool safe = (fabs(p.h2) > small) && (fabs(p.h2) < big) && (fabs(p.u) < big) && (fabs(p.v) < big);
+    if (!safe) { // extreme magnitudes (or NaN): plain IEEE divisions
+        p.u = p.h0 / p.h2;
+        p.v = p.h1 / p.h2;
+    }
     const bool behind = (p.pcz <= 0.0);
     const bool outside = (p.u < 0.0) || (p.u >= cam.width) || (p.v < 0.0) || (p.v >= cam.height);
     p.inside = !behind && !outside;
@@ -96,64 +129,85 @@ __device__ __forceinline__ Projected project_point(const double* __restrict__ T,
 // J_proj = [[1/z, 0, -x/z^2], [0, 1/z, -y/z^2]] on p_hat_cam = K p_hat (:345-349).
 // p_hat is the point in camera coordinates (:336-337) -- the same transform as the projection,
 // because the camera state is inv(w_T_c0) (:232).
+// With a pinhole K the entries J0[1] and J1[0] are exactly zero and are not formed.
+template <bool PINHOLE>
 __device__ __forceinline__ void jacobian_rows(const Projected& p, const CameraK& cam, double (&J0)[6],
                                               double (&J1)[6]) {
-    const double zi = 1.0 / p.h2;  // :345
+    const double zi = p.zi;        // :345
     const double zi2 = zi * zi;    // :346
     const double m0 = -p.h0 * zi2; // :348
     const double m1 = -p.h1 * zi2; // :349
-    // A = J_proj @ K  (2x3)
-    const double a00 = zi * cam.k[0] + m0 * cam.k[6];
-    const double a01 = zi * cam.k[1] + m0 * cam.k[7];
-    const double a02 = zi * cam.k[2] + m0 * cam.k[8];
-    const double a10 = zi * cam.k[3] + m1 * cam.k[6];
-    const double a11 = zi * cam.k[4] + m1 * cam.k[7];
-    const double a12 = zi * cam.k[5] + m1 * cam.k[8];
-    // J = A @ [I | -skew(p)],  -skew(p) = [[0, pz, -py], [-pz, 0, px], [py, -px, 0]]
-    J0[0] = a00;
-    J0[1] = a01;
-    J0[2] = a02;
-    J0[3] = a02 * p.pcy - a01 * p.pcz;
-    J0[4] = a00 * p.pcz - a02 * p.pcx;
-    J0[5] = a01 * p.pcx - a00 * p.pcy;
-    J1[0] = a10;
-    J1[1] = a11;
-    J1[2] = a12;
-    J1[3] = a12 * p.pcy - a11 * p.pcz;
-    J1[4] = a10 * p.pcz - a12 * p.pcx;
-    J1[5] = a11 * p.pcx - a10 * p.pcy;
+    // A = J_proj @ K  (2x3);  J = A @ [I | -skew(p)],  -skew(p) = [[0, pz, -py], [-pz, 0, px], [py, -px, 0]]
+    if (PINHOLE) {
+        const double a00 = zi * cam.k[0];
+        const double a02 = zi * cam.k[2] + m0 * cam.k[8];
+        const double a11 = zi * cam.k[4];
+        const double a12 = zi * cam.k[5] + m1 * cam.k[8];
+        J0[0] = a00;
+        J0[1] = 0.0;
+        J0[2] = a02;
+        J0[3] = a02 * p.pcy;
+        J0[4] = a00 * p.pcz - a02 * p.pcx;
+        J0[5] = -(a00 * p.pcy);
+        J1[0] = 0.0;
+        J1[1] = a11;
+        J1[2] = a12;
+        J1[3] = a12 * p.pcy - a11 * p.pcz;
+        J1[4] = -(a12 * p.pcx);
+        J1[5] = a11 * p.pcx;
+    } else {
+        const double a00 = zi * cam.k[0] + m0 * cam.k[6];
+        const double a01 = zi * cam.k[1] + m0 * cam.k[7];
+        const double a02 = zi * cam.k[2] + m0 * cam.k[8];
+        const double a10 = zi * cam.k[3] + m1 * cam.k[6];
+        const double a11 = zi * cam.k[4] + m1 * cam.k[7];
+        const double a12 = zi * cam.k[5] + m1 * cam.k[8];
+        J0[0] = a00;
+        J0[1] = a01;
+        J0[2] = a02;
+        J0[3] = a02 * p.pcy - a01 * p.pcz;
+        J0[4] = a00 * p.pcz - a02 * p.pcx;
+        J0[5] = a01 * p.pcx - a00 * p.pcy;
+        J1[0] = a10;
+        J1[1] = a11;
+        J1[2] = a12;
+        J1[3] = a12 * p.pcy - a11 * p.pcz;
+        J1[4] = a10 * p.pcz - a12 * p.pcx;
+        J1[5] = a11 * p.pcx - a10 * p.pcy;
+    }
 }
 
-// Sums of one candidate inlier set: upper triangle of H, b, sum of chi, member count.
+// Sums of one candidate inlier set: upper triangle of H and b.
 struct SetSums {
     double H[21];
     double b[6];
-    double chi;
-    unsigned n;
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int i = 0; i < 21; ++i) H[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) b[i] = 0.0;
-        chi = 0.0;
-        n = 0u;
     }
-    // H += J^T J, b += J^T e  (src/ProjectiveICP.py:316-317)
-    __device__ __forceinline__ void add(const double (&J0)[6], const double (&J1)[6], double e0, double e1,
-                                        double c) {
+    // H += J^T J, b += J^T e  (src/ProjectiveICP.py:316-317).  With a pinhole K, J0[1] and J1[0]
+    // are zero: their products are skipped (40 fused multiply-adds instead of 54).
+    template <bool PINHOLE>
+    __device__ __forceinline__ void add(const double (&J0)[6], const double (&J1)[6], double e0, double e1) {
         int k = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
             for (int j = i; j < 6; ++j) {
-                H[k] += J0[i] * J0[j] + J1[i] * J1[j];
+                const bool row0 = !(PINHOLE && (i == 1 || j == 1));
+                const bool row1 = !(PINHOLE && (i == 0 || j == 0));
+                if (row0) H[k] = __builtin_fma(J0[i], J0[j], H[k]);
+                if (row1) H[k] = __builtin_fma(J1[i], J1[j], H[k]);
                 ++k;
             }
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) b[i] += J0[i] * e0 + J1[i] * e1;
-        chi += c;
-        n += 1u;
+        for (int i = 0; i < 6; ++i) {
+            if (!(PINHOLE && i == 1)) b[i] = __builtin_fma(J0[i], e0, b[i]);
+            if (!(PINHOLE && i == 0)) b[i] = __builtin_fma(J1[i], e1, b[i]);
+        }
     }
 };
 
@@ -164,25 +218,110 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Column sums of a 64 x 64 matrix held one row per lane: v[j] of lane l is element (l, j); on
+// return lane l holds sum over all lanes of v[l].  Six halving steps: at the step for lane-id bit
+// b a lane keeps the half of its values that its own bit selects and receives the partner
+// lane's partial sums of that same half, so the work halves every step (about 250
+// instructions for 64 values instead of 64 full butterflies).  Bits 5 and 4 use the gfx950 lane
+// swaps (v_permlane32_swap / v_permlane16_swap), bits 3..0 DPP row_mirror, row_half_mirror and
+// quad permutes, all of which pair a lane with one whose bit b differs and whose higher bits agree.
+// The order of additions is fixed, so the result is reproducible.
+__device__ __forceinline__ double wave_column_sums(double (&v)[64]) {
+    const int lane = threadIdx.x & 63;
+    // bit 5
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const u32x2_t lo = __builtin_amdgcn_permlane32_swap(__double2loint(v[i]), __double2loint(v[i + 32]), false, false);
+        const u32x2_t hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v[i]), __double2hiint(v[i + 32]), false, false);
+        v[i] = __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+    }
+    // bit 4
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const u32x2_t lo = __builtin_amdgcn_permlane16_swap(__double2loint(v[i]), __double2loint(v[i + 16]), false, false);
+        const u32x2_t hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v[i]), __double2hiint(v[i + 16]), false, false);
+        v[i] = __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+    }
+    // bit 3: partner = 15 - (lane % 16) within the row
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double keep = up ? v[i + 8] : v[i];
+            const double send = up ? v[i] : v[i + 8];
+            v[i] = keep + dpp_move<0x140>(send); // row_mirror
+        }
+    }
+    // bit 2: partner = 7 - (lane % 8) within the half row
+    {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double keep = up ? v[i + 4] : v[i];
+            const double send = up ? v[i] : v[i + 4];
+            v[i] = keep + dpp_move<0x141>(send); // row_half_mirror
+        }
+    }
+    // bit 1: partner = lane ^ 2
+    {
+        const bool up = (lane & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double keep = up ? v[i + 2] : v[i];
+            const double send = up ? v[i] : v[i + 2];
+            v[i] = keep + dpp_move<0x4E>(send); // quad_perm [2,3,0,1]
+        }
+    }
+    // bit 0: partner = lane ^ 1
+    {
+        const bool up = (lane & 1) != 0;
+        const double keep = up ? v[1] : v[0];
+        const double send = up ? v[0] : v[1];
+        v[0] = keep + dpp_move<0xB1>(send); // quad_perm [1,0,3,2]
+    }
+    return v[0];
+}
+
 // Sums NV per-thread values over a workgroup of NT threads (NT a multiple of 64, <= 1024).
-// lds: at least (NT/64)*NV doubles.  On return every thread of wave 0 with tid < NV holds the
-// workgroup total of value tid in `out` (other threads: unspecified).  The order of additions is
-// fixed (butterfly inside a wave, then waves 0,1,2,.. in order), so results are reproducible.
+// lds: at least (NT/64)*64 doubles.  On return every thread with tid < NV holds the workgroup
+// total of value tid (other threads: unspecified).  Fixed order of additions: wave_column_sums
+// inside each wave, then waves 0,1,2,.. in order.
 template <int NV, int NT>
 __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* lds) {
-    static_assert(NV <= 64, "one lane of wave 0 per value");
+    static_assert(NV <= 64, "one lane per value");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const double s = wave_sum(vals[i]);
-        if (lane == 0) lds[wave * NV + i] = s;
-    }
-    __syncthreads();
     double out = 0.0;
-    if (threadIdx.x < NV) {
+    if (NV > 8) {
+        double v[64];
 #pragma unroll
-        for (int w = 0; w < NT / 64; ++w) out += lds[w * NV + threadIdx.x];
+        for (int i = 0; i < 64; ++i) v[i] = (i < NV) ? vals[i] : 0.0;
+        lds[wave * 64 + lane] = wave_column_sums(v);
+        __syncthreads();
+        if (threadIdx.x < NV) {
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) out += lds[w * 64 + threadIdx.x];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const double s = wave_sum(vals[i]);
+            if (lane == 0) lds[wave * 64 + i] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < NV) {
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) out += lds[w * 64 + threadIdx.x];
+        }
     }
     __syncthreads();
     return out;
@@ -336,15 +475,56 @@ __device__ inline void damped_solve6(const double* H /*36, symmetric*/, const do
     }
 }
 
+// float32 sine and cosine exactly as numpy computes them on x86 with FMA (its AVX2 / AVX-512
+// float32 loops, which also serve scalars): Cody-Waite reduction by pi/2 in three float32 pieces,
+// then degree-9 / degree-8 polynomials, all in float32 with fused multiply-adds where numpy uses
+// them.  The reference's v2T takes np.cos / np.sin of float32 angles (src/geometry_utils.py:41),
+// and these functions are not correctly rounded (for |x| ~ 1 about one result in ten differs from
+// the rounded float64 value), so matching the reference's poses to 1e-9 needs the same
+// arithmetic, not a more accurate one.  Beyond numpy's Cody-Waite range (|x| > 71476 for cos,
+// 117435 for sin) numpy defers to libm; there the float64 function rounded to float32 is used.
+__device__ inline void numpy_sincosf(float x, float* sin_out, float* cos_out) {
+#pragma clang fp contract(off)
+    const float two_over_pi = 0x1.45f306p-1f, magic = 0x1.8p+23f;
+    const float pio2_hi = -0x1.921fb0p+00f, pio2_med = -0x1.5110b4p-22f, pio2_lo = -0x1.846988p-48f;
+    float q = x * two_over_pi;
+    q = q + magic; // round to nearest integer
+    q = q - magic;
+    float r = __builtin_fmaf(q, pio2_hi, x);
+    r = __builtin_fmaf(q, pio2_med, r);
+    r = __builtin_fmaf(q, pio2_lo, r);
+    const float r2 = r * r;
+    float c = __builtin_fmaf(0x1.98e616p-16f, r2, -0x1.6c06dcp-10f);
+    c = __builtin_fmaf(c, r2, 0x1.55553cp-05f);
+    c = __builtin_fmaf(c, r2, -0x1.000000p-01f);
+    c = __builtin_fmaf(c, r2, 0x1.000000p+00f);
+    float sn = __builtin_fmaf(0x1.7d3bbcp-19f, r2, -0x1.a06bbap-13f);
+    sn = __builtin_fmaf(sn, r2, 0x1.11119ap-07f);
+    sn = __builtin_fmaf(sn, r2, -0x1.555556p-03f);
+    sn = __builtin_fmaf(sn, r2, 0.0f);
+    sn = __builtin_fmaf(sn, r, r);
+    const int iq = (int)q;
+    float s_res = ((iq & 1) == 0) ? sn : c;
+    s_res = ((iq & 2) == 2) ? (0.0f - s_res) : s_res;
+    const int iqc = iq + 1;
+    float c_res = ((iqc & 1) == 0) ? sn : c;
+    c_res = ((iqc & 2) == 2) ? (0.0f - c_res) : c_res;
+    const float ax = fabsf(x);
+    if (!(ax <= 117435.992f)) s_res = (float)sin((double)x);
+    if (!(ax <= 71476.0625f)) c_res = (float)cos((double)x);
+    *sin_out = s_res;
+    *cos_out = c_res;
+}
+
 // v2T (src/geometry_utils.py:38-45): translation copied; R = Rx Ry Rz (:19-23) where the angles
 // are first cast to float32 (:41) so each sine/cosine is a float32 value, widened to float64
-// before the two 3x3 products.  float32 sin/cos are taken as the float64 result rounded to
-// float32 (what numpy returns for these magnitudes).
+// before the two 3x3 products.
 __device__ inline void v2T_device(const double* v, double* T) {
-    const float ax = (float)v[3], ay = (float)v[4], az = (float)v[5];
-    const double cx = (double)(float)cos((double)ax), sx = (double)(float)sin((double)ax);
-    const double cy = (double)(float)cos((double)ay), sy = (double)(float)sin((double)ay);
-    const double cz = (double)(float)cos((double)az), sz = (double)(float)sin((double)az);
+    float fsx, fcx, fsy, fcy, fsz, fcz;
+    numpy_sincosf((float)v[3], &fsx, &fcx);
+    numpy_sincosf((float)v[4], &fsy, &fcy);
+    numpy_sincosf((float)v[5], &fsz, &fcz);
+    const double cx = fcx, sx = fsx, cy = fcy, sy = fsy, cz = fcz, sz = fsz;
     const double Rx[9] = {1.0, 0.0, 0.0, 0.0, cx, -sx, 0.0, sx, cx};
     const double Ry[9] = {cy, 0.0, sy, 0.0, 1.0, 0.0, -sy, 0.0, cy};
     const double Rz[9] = {cz, -sz, 0.0, sz, cz, 0.0, 0.0, 0.0, 1.0};
@@ -437,7 +617,7 @@ __device__ inline void solve_and_schedule(double* st, const double* s1, const do
             r.error = d_inf();
         } else {
             r.mean_stage1 = s1[S1_SUM_CHI] / n1;
-            const double nf = s2[S2_N_F], nr = s2[S2_N_R];
+            const double nf = s2[S2_N_F];
             r.n_stage2 = nf;
             const bool use_f = (nf >= (double)sc.min_inliers); // :307
             r.used_stage2 = use_f ? 1.0 : 0.0;
@@ -447,20 +627,20 @@ __device__ inline void solve_and_schedule(double* st, const double* s1, const do
             for (int i = 0; i < 6; ++i) {
 #pragma unroll
                 for (int j = i; j < 6; ++j) {
-                    const double h = use_f ? s2[S2_HF + k] : (s2[S2_HF + k] + s2[S2_HR + k]);
+                    const double h = use_f ? s2[S2_HF + k] : s2[S2_HA + k];
                     r.H[i * 6 + j] = h;
                     r.H[j * 6 + i] = h;
                     ++k;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) r.b[i] = use_f ? s2[S2_BF + i] : (s2[S2_BF + i] + s2[S2_BR + i]);
+            for (int i = 0; i < 6; ++i) r.b[i] = use_f ? s2[S2_BF + i] : s2[S2_BA + i];
             if (use_f) {
                 r.n_inliers = nf;
                 chi_sum = s2[S2_CHI_F];
             } else {
-                r.n_inliers = nf + nr;
-                chi_sum = s2[S2_CHI_F] + s2[S2_CHI_R];
+                r.n_inliers = n1;
+                chi_sum = s1[S1_SUM_CHI];
             }
             r.error = (r.n_inliers > 0.0) ? chi_sum / r.n_inliers : d_inf(); // :319-321
         }

@@ -30,9 +30,10 @@ struct Stage1Sums {
     unsigned n1, n_inside;
 };
 
+template <bool PINHOLE>
 __device__ __forceinline__ void stage1_point(const double* __restrict__ T, const CameraK& cam, double thr, double mu,
                                              double mv, double x, double y, double z, Stage1Sums& s) {
-    const Projected p = project_point(T, cam, x, y, z);
+    const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
     const double e0 = mu - p.u, e1 = mv - p.v;         // src/ProjectiveICP.py:333
     const double chi = e0 * e0 + e1 * e1;              // :293
     const bool keep = p.inside && (chi <= thr);        // :290, :294
@@ -41,19 +42,29 @@ __device__ __forceinline__ void stage1_point(const double* __restrict__ T, const
     s.sum_chi += keep ? chi : 0.0;
 }
 
-template <int VEC>
-__global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u, const double* __restrict__ v,
-                                                    const double* __restrict__ x, const double* __restrict__ y,
-                                                    const double* __restrict__ z, int64_t M,
-                                                    const double* __restrict__ state, CameraK cam,
-                                                    double* __restrict__ part) {
-    __shared__ double lds[(NT / 64) * 3];
-    if (state[ST_STOP] != 0.0) return;
-    double T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = state[ST_C_T_W + i];
-    const double thr = state[ST_THR];
-    Stage1Sums s{0.0, 0u, 0u};
+// Five 16-byte loads = two correspondences per lane.
+struct Corr2 {
+    double2 u, v, x, y, z;
+};
+__device__ __forceinline__ Corr2 load2(const double2* __restrict__ u, const double2* __restrict__ v,
+                                       const double2* __restrict__ x, const double2* __restrict__ y,
+                                       const double2* __restrict__ z, int64_t i) {
+    Corr2 c;
+    c.u = u[i];
+    c.v = v[i];
+    c.x = x[i];
+    c.y = y[i];
+    c.z = z[i];
+    return c;
+}
+
+// Streams the correspondences through `point(mu, mv, x, y, z)`.  VEC == 2: 16-byte loads, the
+// loads of the next grid-stride step are issued before the current pair is processed, so a wave
+// always has a full step of HBM requests in flight while it computes.
+template <int VEC, typename F>
+__device__ __forceinline__ void for_each_correspondence(const double* __restrict__ u, const double* __restrict__ v,
+                                                        const double* __restrict__ x, const double* __restrict__ y,
+                                                        const double* __restrict__ z, int64_t M, F&& point) {
     const int64_t stride = (int64_t)gridDim.x * NT;
     const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (VEC == 2) {
@@ -63,15 +74,43 @@ __global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u
         const double2* x2 = reinterpret_cast<const double2*>(x);
         const double2* y2 = reinterpret_cast<const double2*>(y);
         const double2* z2 = reinterpret_cast<const double2*>(z);
-        for (int64_t i = tid; i < n2; i += stride) {
-            const double2 a = u2[i], b = v2[i], c = x2[i], d = y2[i], e = z2[i];
-            stage1_point(T, cam, thr, a.x, b.x, c.x, d.x, e.x, s);
-            stage1_point(T, cam, thr, a.y, b.y, c.y, d.y, e.y, s);
+        int64_t i = tid;
+        if (i < n2) {
+            Corr2 cur = load2(u2, v2, x2, y2, z2, i);
+            for (;;) {
+                const int64_t nxt = i + stride;
+                const bool more = nxt < n2;
+                Corr2 pre;
+                if (more) pre = load2(u2, v2, x2, y2, z2, nxt);
+                point(cur.u.x, cur.v.x, cur.x.x, cur.y.x, cur.z.x);
+                point(cur.u.y, cur.v.y, cur.x.y, cur.y.y, cur.z.y);
+                if (!more) break;
+                cur = pre;
+                i = nxt;
+            }
         }
-        if ((M & 1) && tid == 0) stage1_point(T, cam, thr, u[M - 1], v[M - 1], x[M - 1], y[M - 1], z[M - 1], s);
+        if ((M & 1) && tid == 0) point(u[M - 1], v[M - 1], x[M - 1], y[M - 1], z[M - 1]);
     } else {
-        for (int64_t i = tid; i < M; i += stride) stage1_point(T, cam, thr, u[i], v[i], x[i], y[i], z[i], s);
+        for (int64_t i = tid; i < M; i += stride) point(u[i], v[i], x[i], y[i], z[i]);
     }
+}
+
+template <int VEC, bool PINHOLE>
+__global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u, const double* __restrict__ v,
+                                                    const double* __restrict__ x, const double* __restrict__ y,
+                                                    const double* __restrict__ z, int64_t M,
+                                                    const double* __restrict__ state, CameraK cam,
+                                                    double* __restrict__ part) {
+    __shared__ double lds[(NT / 64) * 64];
+    if (state[ST_STOP] != 0.0) return;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = state[ST_C_T_W + i];
+    const double thr = state[ST_THR];
+    Stage1Sums s{0.0, 0u, 0u};
+    for_each_correspondence<VEC>(u, v, x, y, z, M, [&](double mu, double mv, double px, double py, double pz) {
+        stage1_point<PINHOLE>(T, cam, thr, mu, mv, px, py, pz, s);
+    });
     const double vals[3] = {s.sum_chi, (double)s.n1, (double)s.n_inside};
     const double tot = block_sum<3, NT>(vals, lds);
     if (threadIdx.x < 3) part[(size_t)blockIdx.x * PICP_S1_DOUBLES + threadIdx.x] = tot;
@@ -79,48 +118,54 @@ __global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u
 }
 
 // ---- stage 2 --------------------------------------------------------------------------------
+struct Stage2Sums {
+    SetSums F, A;
+    double chi_f;
+    unsigned n_f;
+};
+
+template <bool PINHOLE>
 __device__ __forceinline__ void stage2_point(const double* __restrict__ T, const CameraK& cam, double thr, double mean,
-                                             double mu, double mv, double x, double y, double z, SetSums& F,
-                                             SetSums& R) {
-    const Projected p = project_point(T, cam, x, y, z);
+                                             double mu, double mv, double x, double y, double z, Stage2Sums& s) {
+    const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
     const double e0 = mu - p.u, e1 = mv - p.v;
     const double chi = e0 * e0 + e1 * e1;
     const bool keep = p.inside && (chi <= thr);
     if (keep) {
         double J0[6], J1[6];
-        jacobian_rows(p, cam, J0, J1);
-        if (chi < mean) // src/ProjectiveICP.py:302 (strict)
-            F.add(J0, J1, e0, e1, chi);
-        else
-            R.add(J0, J1, e0, e1, chi);
+        jacobian_rows<PINHOLE>(p, cam, J0, J1);
+        s.A.add<PINHOLE>(J0, J1, e0, e1);
+        if (chi < mean) { // src/ProjectiveICP.py:302 (strict)
+            s.F.add<PINHOLE>(J0, J1, e0, e1);
+            s.chi_f += chi;
+            s.n_f += 1u;
+        }
     }
 }
 
-__device__ __forceinline__ void pack_sets(const SetSums& F, const SetSums& R, double (&vals)[S2_USED]) {
+__device__ __forceinline__ void pack_sets(const Stage2Sums& s, double (&vals)[S2_USED]) {
 #pragma unroll
     for (int i = 0; i < 21; ++i) {
-        vals[S2_HF + i] = F.H[i];
-        vals[S2_HR + i] = R.H[i];
+        vals[S2_HF + i] = s.F.H[i];
+        vals[S2_HA + i] = s.A.H[i];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        vals[S2_BF + i] = F.b[i];
-        vals[S2_BR + i] = R.b[i];
+        vals[S2_BF + i] = s.F.b[i];
+        vals[S2_BA + i] = s.A.b[i];
     }
-    vals[S2_CHI_F] = F.chi;
-    vals[S2_N_F] = (double)F.n;
-    vals[S2_CHI_R] = R.chi;
-    vals[S2_N_R] = (double)R.n;
+    vals[S2_CHI_F] = s.chi_f;
+    vals[S2_N_F] = (double)s.n_f;
 }
 
-template <int VEC>
+template <int VEC, bool PINHOLE>
 __global__ __launch_bounds__(NT) void stage2_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                     const double* __restrict__ x, const double* __restrict__ y,
                                                     const double* __restrict__ z, int64_t M,
                                                     const double* __restrict__ state, CameraK cam,
                                                     const double* __restrict__ s1part, int s1rows,
                                                     double* __restrict__ part) {
-    __shared__ double lds[(NT / 64) * S2_USED > NT ? (NT / 64) * S2_USED : NT];
+    __shared__ double lds[(NT / 64) * 64];
     __shared__ double s1[PICP_S1_DOUBLES];
     if (state[ST_STOP] != 0.0) return;
     {
@@ -139,30 +184,16 @@ __global__ __launch_bounds__(NT) void stage2_kernel(const double* __restrict__ u
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = state[ST_C_T_W + i];
     const double thr = state[ST_THR];
-    SetSums F, R;
-    F.clear();
-    R.clear();
-    const int64_t stride = (int64_t)gridDim.x * NT;
-    const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (VEC == 2) {
-        const int64_t n2 = M >> 1;
-        const double2* u2 = reinterpret_cast<const double2*>(u);
-        const double2* v2 = reinterpret_cast<const double2*>(v);
-        const double2* x2 = reinterpret_cast<const double2*>(x);
-        const double2* y2 = reinterpret_cast<const double2*>(y);
-        const double2* z2 = reinterpret_cast<const double2*>(z);
-        for (int64_t i = tid; i < n2; i += stride) {
-            const double2 a = u2[i], b = v2[i], c = x2[i], d = y2[i], e = z2[i];
-            stage2_point(T, cam, thr, mean, a.x, b.x, c.x, d.x, e.x, F, R);
-            stage2_point(T, cam, thr, mean, a.y, b.y, c.y, d.y, e.y, F, R);
-        }
-        if ((M & 1) && tid == 0)
-            stage2_point(T, cam, thr, mean, u[M - 1], v[M - 1], x[M - 1], y[M - 1], z[M - 1], F, R);
-    } else {
-        for (int64_t i = tid; i < M; i += stride) stage2_point(T, cam, thr, mean, u[i], v[i], x[i], y[i], z[i], F, R);
-    }
+    Stage2Sums s;
+    s.F.clear();
+    s.A.clear();
+    s.chi_f = 0.0;
+    s.n_f = 0u;
+    for_each_correspondence<VEC>(u, v, x, y, z, M, [&](double mu, double mv, double px, double py, double pz) {
+        stage2_point<PINHOLE>(T, cam, thr, mean, mu, mv, px, py, pz, s);
+    });
     double vals[S2_USED];
-    pack_sets(F, R, vals);
+    pack_sets(s, vals);
     const double tot = block_sum<S2_USED, NT>(vals, lds);
     if (threadIdx.x < S2_USED) row[threadIdx.x] = tot;
     else if (threadIdx.x < PICP_S2_DOUBLES) row[threadIdx.x] = 0.0;
@@ -209,7 +240,7 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
 // ---- whole loop in one workgroup, one problem per workgroup -------------------------------------
 // R > 0: each thread keeps up to R correspondences in registers for the whole loop, so the data
 // is read from HBM once per problem.  R == 0: any size, re-read (from cache) every iteration.
-template <int R>
+template <int R, bool PINHOLE>
 __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                          const double* __restrict__ x, const double* __restrict__ y,
                                                          const double* __restrict__ z,
@@ -218,7 +249,7 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
                                                          picp_schedule sc, picp_result* __restrict__ results,
                                                          double* __restrict__ hist, int hist_rows) {
     __shared__ double st[PICP_STATE_DOUBLES];
-    __shared__ double lds[(NT / 64) * S2_USED > NT ? (NT / 64) * S2_USED : NT];
+    __shared__ double lds[(NT / 64) * 64];
     __shared__ double s1[PICP_S1_DOUBLES];
     __shared__ double s2[PICP_S2_DOUBLES];
     const int prob = blockIdx.x;
@@ -250,10 +281,11 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
         if (R > 0) {
 #pragma unroll
             for (int r = 0; r < RR; ++r)
-                if (r * NT + (int)threadIdx.x < cnt) stage1_point(T, cam, thr, ru[r], rv[r], rx[r], ry[r], rz[r], a);
+                if (r * NT + (int)threadIdx.x < cnt)
+                    stage1_point<PINHOLE>(T, cam, thr, ru[r], rv[r], rx[r], ry[r], rz[r], a);
         } else {
             for (int i = threadIdx.x; i < cnt; i += NT)
-                stage1_point(T, cam, thr, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], a);
+                stage1_point<PINHOLE>(T, cam, thr, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], a);
         }
         {
             const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
@@ -264,20 +296,22 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
         const double n1 = s1[S1_COUNT];
         if (n1 != 0.0) {
             const double mean = s1[S1_SUM_CHI] / n1;
-            SetSums F, Rs;
-            F.clear();
-            Rs.clear();
+            Stage2Sums s;
+            s.F.clear();
+            s.A.clear();
+            s.chi_f = 0.0;
+            s.n_f = 0u;
             if (R > 0) {
 #pragma unroll
                 for (int r = 0; r < RR; ++r)
                     if (r * NT + (int)threadIdx.x < cnt)
-                        stage2_point(T, cam, thr, mean, ru[r], rv[r], rx[r], ry[r], rz[r], F, Rs);
+                        stage2_point<PINHOLE>(T, cam, thr, mean, ru[r], rv[r], rx[r], ry[r], rz[r], s);
             } else {
                 for (int i = threadIdx.x; i < cnt; i += NT)
-                    stage2_point(T, cam, thr, mean, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], F, Rs);
+                    stage2_point<PINHOLE>(T, cam, thr, mean, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], s);
             }
             double vals[S2_USED];
-            pack_sets(F, Rs, vals);
+            pack_sets(s, vals);
             const double tot = block_sum<S2_USED, NT>(vals, lds);
             if (threadIdx.x < S2_USED) s2[threadIdx.x] = tot;
             __syncthreads();
@@ -367,10 +401,9 @@ int picp_stage1(picp_ctx* ctx, const double* u, const double* v, const double* x
     const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
     const int grid = grid_for(ctx, vec ? (M + 1) / 2 : M, 1);
     ctx->rows1 = grid;
-    if (vec)
-        hipLaunchKernelGGL(stage1_kernel<2>, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, ctx->part1);
-    else
-        hipLaunchKernelGGL(stage1_kernel<1>, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, ctx->part1);
+    auto kern = vec ? (is_pinhole(cam->K) ? stage1_kernel<2, true> : stage1_kernel<2, false>)
+                    : (is_pinhole(cam->K) ? stage1_kernel<1, true> : stage1_kernel<1, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, ctx->part1);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
 }
@@ -395,12 +428,10 @@ int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x
     ctx->rows2 = grid;
     const double* s1p = s1 ? s1 : ctx->part1;
     const int s1rows = s1 ? 1 : ctx->rows1;
-    if (vec)
-        hipLaunchKernelGGL(stage2_kernel<2>, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p,
-                           s1rows, ctx->part2);
-    else
-        hipLaunchKernelGGL(stage2_kernel<1>, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p,
-                           s1rows, ctx->part2);
+    auto kern = vec ? (is_pinhole(cam->K) ? stage2_kernel<2, true> : stage2_kernel<2, false>)
+                    : (is_pinhole(cam->K) ? stage2_kernel<1, true> : stage2_kernel<1, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p, s1rows,
+                       ctx->part2);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
 }
@@ -495,8 +526,9 @@ int picp_run_batched(picp_ctx* ctx, const double* u, const double* v, const doub
     if (B == 0) return PICP_OK;
     DeviceGuard g(ctx->device);
     const CameraK c = to_device_camera(cam);
-    hipLaunchKernelGGL(icp_batched_kernel<0>, dim3(B), dim3(NT), 0, ctx->stream, u, v, x, y, z, offsets, poses0, c,
-                       *sched, results, hist, (int)hist_rows);
+    auto kern = is_pinhole(cam->K) ? icp_batched_kernel<0, true> : icp_batched_kernel<0, false>;
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), 0, ctx->stream, u, v, x, y, z, offsets, poses0, c, *sched, results,
+                       hist, (int)hist_rows);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
 }
@@ -540,13 +572,13 @@ int picp_linearize(picp_ctx* ctx, const double* u, const double* v, const double
     int k = 0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j, ++k) {
-            const double hv = use_f ? hs2[S2_HF + k] : hs2[S2_HF + k] + hs2[S2_HR + k];
+            const double hv = use_f ? hs2[S2_HF + k] : hs2[S2_HA + k];
             H[i * 6 + j] = hv;
             H[j * 6 + i] = hv;
         }
-    for (int i = 0; i < 6; ++i) b[i] = use_f ? hs2[S2_BF + i] : hs2[S2_BF + i] + hs2[S2_BR + i];
-    const double n = use_f ? hs2[S2_N_F] : hs2[S2_N_F] + hs2[S2_N_R];
-    const double chi = use_f ? hs2[S2_CHI_F] : hs2[S2_CHI_F] + hs2[S2_CHI_R];
+    for (int i = 0; i < 6; ++i) b[i] = use_f ? hs2[S2_BF + i] : hs2[S2_BA + i];
+    const double n = use_f ? hs2[S2_N_F] : hs1[S1_COUNT];
+    const double chi = use_f ? hs2[S2_CHI_F] : hs1[S1_SUM_CHI];
     *num_inliers = (int64_t)n;
     *error = n > 0.0 ? chi / n : __builtin_inf();
     return PICP_OK;
