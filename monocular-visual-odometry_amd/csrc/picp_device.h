@@ -98,9 +98,7 @@ __device__ __forceinline__ Projected project_point(const double* __restrict__ T,
     p.pcx = T[0] * x + T[1] * y + T[2] * z + T[3];
     p.pcy = T[4] * x + T[5] * y + T[6] * z + T[7];
     p.pcz = T[8] * x + T[9] * y + T[10] * z + T[11];
-    // 0 * inf is NaN: with non-finite coordinates the zero entries of K matter, so those points
-    // take the full products too
-    if (PINHOLE && __builtin_isfinite(p.pcx + p.pcy + p.pcz)) {
+    if (PINHOLE) {
         p.h0 = cam.k[0] * p.pcx + cam.k[2] * p.pcz;
         p.h1 = cam.k[4] * p.pcy + cam.k[5] * p.pcz;
         p.h2 = cam.k[8] * p.pcz;
@@ -113,8 +111,14 @@ __device__ __forceinline__ Projected project_point(const double* __restrict__ T,
     p.u = div_with_recip(p.h0, p.h2, p.zi);
     p.v = div_with_recip(p.h1, p.h2, p.zi);
     const double big = 1e150, small = 1e-150;
-    const bool safe = (fabs(p.h2) > small) && (fabs(p.h2) < big) && (fabs(p.u) < big) && (fabs(p.v) < big);
-    if (!safe) { // extreme magnitudes (or NaN): plain IEEE divisions
+    const bool safe = (fabs(p.h2) > small) && (fabs(p.h2) < big) && (fabs(p.u) + fabs(p.v) < big);
+    if (!safe) {
+        // Extreme magnitudes, infinities or NaN (never the case for real map points): the full
+        // products with K (0 * inf is NaN, so K's zero entries matter here) and plain IEEE divisions.
+        p.h0 = cam.k[0] * p.pcx + cam.k[1] * p.pcy + cam.k[2] * p.pcz;
+        p.h1 = cam.k[3] * p.pcx + cam.k[4] * p.pcy + cam.k[5] * p.pcz;
+        p.h2 = cam.k[6] * p.pcx + cam.k[7] * p.pcy + cam.k[8] * p.pcz;
+        p.zi = 1.0 / p.h2;
         p.u = p.h0 / p.h2;
         p.v = p.h1 / p.h2;
     }

@@ -74,19 +74,28 @@ __device__ __forceinline__ void for_each_correspondence(const double* __restrict
         const double2* x2 = reinterpret_cast<const double2*>(x);
         const double2* y2 = reinterpret_cast<const double2*>(y);
         const double2* z2 = reinterpret_cast<const double2*>(z);
+        // Two register sets in ping-pong: while set A is processed the loads of set B are in
+        // flight and vice versa, with no register copies between steps.  The prefetch is
+        // unconditional (past the end it re-reads the current step, a cache hit whose data is
+        // dropped): a load under a lane-dependent branch would make the compiler wait for every
+        // outstanding load at the join, the prefetched ones included.
         int64_t i = tid;
         if (i < n2) {
-            Corr2 cur = load2(u2, v2, x2, y2, z2, i);
+            Corr2 A = load2(u2, v2, x2, y2, z2, i), B;
             for (;;) {
-                const int64_t nxt = i + stride;
-                const bool more = nxt < n2;
-                Corr2 pre;
-                if (more) pre = load2(u2, v2, x2, y2, z2, nxt);
-                point(cur.u.x, cur.v.x, cur.x.x, cur.y.x, cur.z.x);
-                point(cur.u.y, cur.v.y, cur.x.y, cur.y.y, cur.z.y);
-                if (!more) break;
-                cur = pre;
-                i = nxt;
+                const int64_t j = i + stride;
+                const bool hasB = j < n2;
+                B = load2(u2, v2, x2, y2, z2, hasB ? j : i);
+                point(A.u.x, A.v.x, A.x.x, A.y.x, A.z.x);
+                point(A.u.y, A.v.y, A.x.y, A.y.y, A.z.y);
+                if (!hasB) break;
+                const int64_t k = j + stride;
+                const bool hasA = k < n2;
+                A = load2(u2, v2, x2, y2, z2, hasA ? k : j);
+                point(B.u.x, B.v.x, B.x.x, B.y.x, B.z.x);
+                point(B.u.y, B.v.y, B.x.y, B.y.y, B.z.y);
+                if (!hasA) break;
+                i = k;
             }
         }
         if ((M & 1) && tid == 0) point(u[M - 1], v[M - 1], x[M - 1], y[M - 1], z[M - 1]);
