@@ -12,7 +12,7 @@ from .Camera import Camera
 from .Data import Data
 from .ProjectiveICP import ProjectiveICP
 from .data_association import data_association_on_appearance
-from .geometry_utils import Rt2T, transform
+from .evaluation import trajectory_errors
 
 
 class VisualOdometry:
@@ -63,37 +63,10 @@ class VisualOdometry:
         return total_time, mean_time_per_frame
 
     def compute_errors(self):
-        """The numbers behind errors.dat  (src/VisualOdometry.py:97-157).
-
-        Returns a dict with per-frame 'rotation_error', 'rotation_ratio', 'translation_error',
-        'translation_ratio', the global 'scale', and the scaled 'trajectory' / 'world_points' in the
-        robot-world frame."""
-        gt_trajectory = self.ProjectiveICP.get_data().get_trajectory_data_poses()
-        estimated_trajectory = self.ProjectiveICP.get_trajectory()
-        estimated_world_points = self.ProjectiveICP.get_map()
-        C = np.asarray(self.ProjectiveICP.get_camera().get_camera_transform(), dtype=np.float64)
-        T = gt_trajectory[self.__initial_frame] @ Rt2T(R=C[:3, :3], t=np.zeros(3)) if self.__initial_frame > 0 else C
-        est = transform(estimated_trajectory, T)
-        pts = transform(estimated_world_points['position'], T, are_points=True)
-        rot_err, rot_ratio, tr_err, tr_ratio = [], [], [], []
-        for i in range(len(est) - 1):
-            rel_est = np.linalg.inv(est[i]) @ est[i + 1]
-            rel_gt = np.linalg.inv(gt_trajectory[i]) @ gt_trajectory[i + 1]
-            error_T = np.linalg.inv(rel_est) @ rel_gt
-            error_R = np.round(error_T[:3, :3], 5)                                   # :124
-            with np.errstate(invalid="ignore"):
-                rot_err.append(np.arccos((np.trace(error_R) - 1) / 2))               # :125
-            rot_ratio.append(np.linalg.norm(est[i][:3, :3], 'fro') / np.linalg.norm(gt_trajectory[i][:3, :3], 'fro'))
-            with np.errstate(divide="ignore", invalid="ignore"):
-                ratio = np.linalg.norm(gt_trajectory[i][:3, 3]) / np.linalg.norm(est[i][:3, 3])   # :129
-                tr_ratio.append(ratio)
-                tr_err.append(np.linalg.norm(ratio * est[i][:3, 3] - gt_trajectory[i][:3, 3]))    # :135
-        scale = np.mean(tr_ratio)                                                    # :154
-        return {'rotation_error': rot_err, 'rotation_ratio': rot_ratio, 'translation_error': tr_err,
-                'translation_ratio': tr_ratio, 'scale': scale,
-                'trajectory': transform(est, scale=scale),
-                'world_points': transform(pts, scale=scale, are_points=True),
-                'world_appearance': estimated_world_points['appearance']}
+        """The numbers behind errors.dat (see evaluation.trajectory_errors)."""
+        picp = self.ProjectiveICP
+        return trajectory_errors(picp.get_trajectory(), picp.get_map(), picp.get_data().get_trajectory_data_poses(),
+                                 picp.get_camera().get_camera_transform(), self.__initial_frame)
 
     def evaluate(self, output_dir="outputs/final_results"):
         """Prints the summary and writes errors.dat, estimated_trajectory.dat and

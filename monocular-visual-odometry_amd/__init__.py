@@ -6,7 +6,7 @@ the package name in its imports:  ProjectiveICP, data_association, Camera, Data,
 VisualOdometry.  The compute path is libpicp_hip.so (csrc/, C ABI in include/picp_hip.h); there is
 no CPU fallback for it.
 """
-from . import _lib, geometry_utils, two_view, Camera as _Camera, Data as _Data, data_association  # noqa: F401
+from . import _lib, geometry_utils, two_view, evaluation, Camera as _Camera, Data as _Data, data_association  # noqa: F401
 from . import ProjectiveICP as _ProjectiveICP, VisualOdometry as _VisualOdometry, sharded  # noqa: F401
 from ._lib import Context, PicpError, get_context, load_library  # noqa: F401
 from .data_association import data_association_on_appearance  # noqa: F401

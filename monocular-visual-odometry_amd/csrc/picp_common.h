@@ -13,9 +13,10 @@ struct picp_ctx {
     int device;
     hipStream_t stream;
     int num_cus;
-    int max_blocks;   // rows of the per-workgroup partial-sum buffers
-    double* part1;    // [max_blocks][PICP_S1_DOUBLES]
-    double* part2;    // [max_blocks][PICP_S2_DOUBLES]
+    int max_blocks1;  // workgroups (= partial records) of a stage-1 launch
+    int max_blocks2;  // workgroups (= partial records) of a stage-2 launch
+    double* part1;    // [max_blocks1][PICP_S1_DOUBLES]
+    double* part2;    // [max_blocks2][PICP_S2_DOUBLES]
     int rows1, rows2; // rows written by the last stage-1 / stage-2 launch
     double* scratch;  // small device scratch: state block + s1 + s2 + misc (see offsets below)
     // association workspace, grown on demand

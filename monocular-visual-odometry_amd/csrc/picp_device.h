@@ -372,72 +372,41 @@ __device__ __forceinline__ double fold_partials(const double* __restrict__ part,
 
 // ---- small dense routines used by the solve (one lane) ---------------------------------------
 
-// General 4x4 inverse by LU with partial pivoting applied to the identity, the algorithm behind
-// np.linalg.inv (LAPACK gesv) used at src/ProjectiveICP.py:232.  A rigid-transform shortcut
-// [R^T | -R^T t] is not usable: R is built from float32 sines and cosines
-// (src/geometry_utils.py:41) and is orthonormal only to ~1e-8.
-__device__ inline void invert4x4(const double* A, double* Ainv) {
-    double a[4][4], b[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a[i][j] = A[i * 4 + j];
-            b[i][j] = (i == j) ? 1.0 : 0.0;
-        }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int p = k;
-        double best = fabs(a[k][k]);
-#pragma unroll
-        for (int r = k + 1; r < 4; ++r) {
-            const double c = fabs(a[r][k]);
-            if (c > best) {
-                best = c;
-                p = r;
-            }
-        }
-#pragma unroll
-        for (int r = k + 1; r < 4; ++r) {
-            if (r == p) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    double t = a[k][j];
-                    a[k][j] = a[r][j];
-                    a[r][j] = t;
-                    t = b[k][j];
-                    b[k][j] = b[r][j];
-                    b[r][j] = t;
-                }
-            }
-        }
-        const double pinv = 1.0 / a[k][k];
-        a[k][k] = pinv; // the diagonal holds the pivot reciprocals from here on
-#pragma unroll
-        for (int r = k + 1; r < 4; ++r) {
-            const double f = a[r][k] * pinv;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j > k) a[r][j] -= f * a[k][j];
-                b[r][j] -= f * b[k][j];
-            }
-            a[r][k] = 0.0;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int i = 3; i >= 0; --i) {
-            double s = b[i][j];
-#pragma unroll
-            for (int k = i + 1; k < 4; ++k) s -= a[i][k] * b[k][j];
-            b[i][j] = s * a[i][i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Ainv[i * 4 + j] = b[i][j];
+// Inverse of a pose matrix [A t; 0 0 0 1] as [A^-1, -A^-1 t; 0 0 0 1] with A^-1 = adj(A) / det(A).
+// The reference calls np.linalg.inv (src/ProjectiveICP.py:232), a general LU inverse; a
+// rigid-transform shortcut [A^T | -A^T t] is not usable, because A is built from float32 sines and
+// cosines (src/geometry_utils.py:41) and is orthonormal only to ~1e-8.  A is always within ~1e-7
+// of a rotation, so the cofactor form is as accurate as LU here (a few ulp) and is a short,
+// mostly independent instruction sequence for the single lane that runs it.
+__device__ inline void invert_pose(const double* T, double* Tinv) {
+    const double a = T[0], b = T[1], c = T[2];
+    const double d = T[4], e = T[5], f = T[6];
+    const double g = T[8], h = T[9], i = T[10];
+    const double c00 = e * i - f * h, c01 = c * h - b * i, c02 = b * f - c * e;
+    const double c10 = f * g - d * i, c11 = a * i - c * g, c12 = c * d - a * f;
+    const double c20 = d * h - e * g, c21 = b * g - a * h, c22 = a * e - b * d;
+    const double det = a * c00 + b * c10 + c * c20;
+    const double r = 1.0 / det;
+    const double m00 = c00 * r, m01 = c01 * r, m02 = c02 * r;
+    const double m10 = c10 * r, m11 = c11 * r, m12 = c12 * r;
+    const double m20 = c20 * r, m21 = c21 * r, m22 = c22 * r;
+    const double tx = T[3], ty = T[7], tz = T[11];
+    Tinv[0] = m00;
+    Tinv[1] = m01;
+    Tinv[2] = m02;
+    Tinv[3] = -(m00 * tx + m01 * ty + m02 * tz);
+    Tinv[4] = m10;
+    Tinv[5] = m11;
+    Tinv[6] = m12;
+    Tinv[7] = -(m10 * tx + m11 * ty + m12 * tz);
+    Tinv[8] = m20;
+    Tinv[9] = m21;
+    Tinv[10] = m22;
+    Tinv[11] = -(m20 * tx + m21 * ty + m22 * tz);
+    Tinv[12] = 0.0;
+    Tinv[13] = 0.0;
+    Tinv[14] = 0.0;
+    Tinv[15] = 1.0;
 }
 
 // Solves (H + lambda I) dx = -b for symmetric positive definite H + lambda I by Cholesky.
@@ -702,7 +671,7 @@ __device__ inline void solve_and_schedule(double* st, const double* s1, const do
 
     // state update (:231-238)
     double Tinv[16];
-    invert4x4(T1, Tinv);
+    invert_pose(T1, Tinv);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         st[ST_W_T_C + i] = T1[i];
@@ -754,7 +723,7 @@ __device__ inline void solve_and_schedule(double* st, const double* s1, const do
 // cleared slope statistics and counters.
 __device__ inline void init_state(double* st, const double* pose, double thr, double lambda, int num_iterations) {
     double inv[16];
-    invert4x4(pose, inv);
+    invert_pose(pose, inv);
     for (int i = ST_BEST_IT + 1; i < PICP_STATE_DOUBLES; ++i) st[i] = 0.0;
     for (int i = 0; i < 16; ++i) {
         st[ST_W_T_C + i] = pose[i];

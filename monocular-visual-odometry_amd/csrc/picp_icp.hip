@@ -14,7 +14,9 @@
 
 namespace picp {
 
-constexpr int NT = 256; // threads per workgroup in every kernel of this file
+constexpr int NT = 256;  // threads per workgroup of the stage-1 scan, the batched kernel and the small kernels
+constexpr int NT2 = 512; // stage-2 scan: one workgroup of eight waves per CU (its ~176 registers per lane allow two
+                         // waves per SIMD), so a launch leaves at most one partial record per CU to fold
 
 struct Pose16 {
     double m[16];
@@ -61,12 +63,12 @@ __device__ __forceinline__ Corr2 load2(const double2* __restrict__ u, const doub
 // Streams the correspondences through `point(mu, mv, x, y, z)`.  VEC == 2: 16-byte loads, the
 // loads of the next grid-stride step are issued before the current pair is processed, so a wave
 // always has a full step of HBM requests in flight while it computes.
-template <int VEC, typename F>
+template <int VEC, int THREADS, typename F>
 __device__ __forceinline__ void for_each_correspondence(const double* __restrict__ u, const double* __restrict__ v,
                                                         const double* __restrict__ x, const double* __restrict__ y,
                                                         const double* __restrict__ z, int64_t M, F&& point) {
-    const int64_t stride = (int64_t)gridDim.x * NT;
-    const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * THREADS;
+    const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (VEC == 2) {
         const int64_t n2 = M >> 1;
         const double2* u2 = reinterpret_cast<const double2*>(u);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u
     for (int i = 0; i < 12; ++i) T[i] = state[ST_C_T_W + i];
     const double thr = state[ST_THR];
     Stage1Sums s{0.0, 0u, 0u};
-    for_each_correspondence<VEC>(u, v, x, y, z, M, [&](double mu, double mv, double px, double py, double pz) {
+    for_each_correspondence<VEC, NT>(u, v, x, y, z, M, [&](double mu, double mv, double px, double py, double pz) {
         stage1_point<PINHOLE>(T, cam, thr, mu, mv, px, py, pz, s);
     });
     const double vals[3] = {s.sum_chi, (double)s.n1, (double)s.n_inside};
@@ -168,17 +170,17 @@ __device__ __forceinline__ void pack_sets(const Stage2Sums& s, double (&vals)[S2
 }
 
 template <int VEC, bool PINHOLE>
-__global__ __launch_bounds__(NT) void stage2_kernel(const double* __restrict__ u, const double* __restrict__ v,
+__global__ __launch_bounds__(NT2) void stage2_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                     const double* __restrict__ x, const double* __restrict__ y,
                                                     const double* __restrict__ z, int64_t M,
                                                     const double* __restrict__ state, CameraK cam,
                                                     const double* __restrict__ s1part, int s1rows,
                                                     double* __restrict__ part) {
-    __shared__ double lds[(NT / 64) * 64];
+    __shared__ double lds[(NT2 / 64) * 64];
     __shared__ double s1[PICP_S1_DOUBLES];
     if (state[ST_STOP] != 0.0) return;
     {
-        const double tot = fold_partials<PICP_S1_DOUBLES, NT>(s1part, s1rows, PICP_S1_DOUBLES, lds);
+        const double tot = fold_partials<PICP_S1_DOUBLES, NT2>(s1part, s1rows, PICP_S1_DOUBLES, lds);
         if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = tot;
         __syncthreads();
     }
@@ -198,12 +200,12 @@ __global__ __launch_bounds__(NT) void stage2_kernel(const double* __restrict__ u
     s.A.clear();
     s.chi_f = 0.0;
     s.n_f = 0u;
-    for_each_correspondence<VEC>(u, v, x, y, z, M, [&](double mu, double mv, double px, double py, double pz) {
+    for_each_correspondence<VEC, NT2>(u, v, x, y, z, M, [&](double mu, double mv, double px, double py, double pz) {
         stage2_point<PINHOLE>(T, cam, thr, mean, mu, mv, px, py, pz, s);
     });
     double vals[S2_USED];
     pack_sets(s, vals);
-    const double tot = block_sum<S2_USED, NT>(vals, lds);
+    const double tot = block_sum<S2_USED, NT2>(vals, lds);
     if (threadIdx.x < S2_USED) row[threadIdx.x] = tot;
     else if (threadIdx.x < PICP_S2_DOUBLES) row[threadIdx.x] = 0.0;
 }
@@ -239,11 +241,19 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
         if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = t2;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const int it = (int)state[ST_IT];
-        double* row = (hist != nullptr && it < hist_rows) ? hist + (size_t)it * PICP_HIST_STRIDE : nullptr;
-        solve_and_schedule(state, s1, s2, sc, row);
-    }
+    // The serial step runs on one lane against copies of the state block and the history row in
+    // LDS; both are moved to and from global memory by the whole workgroup, so the lane never
+    // waits on a global-memory round trip between dependent scalar steps.
+    __shared__ double st[PICP_STATE_DOUBLES];
+    __shared__ double row[PICP_HIST_STRIDE];
+    if (threadIdx.x < PICP_STATE_DOUBLES) st[threadIdx.x] = state[threadIdx.x];
+    __syncthreads();
+    const int it = (int)st[ST_IT];
+    const bool record = (hist != nullptr && it < hist_rows);
+    if (threadIdx.x == 0) solve_and_schedule(st, s1, s2, sc, record ? row : nullptr);
+    __syncthreads();
+    if (threadIdx.x < PICP_STATE_DOUBLES) state[threadIdx.x] = st[threadIdx.x];
+    if (record && threadIdx.x < PICP_HIST_STRIDE) hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
 }
 
 // ---- whole loop in one workgroup, one problem per workgroup -------------------------------------
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
 }
 
 __global__ void invert_kernel(const double* in, double* out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) invert4x4(in, out);
+    if (threadIdx.x == 0 && blockIdx.x == 0) invert_pose(in, out);
 }
 __global__ void v2T_kernel(const double* in, double* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) v2T_device(in, out);
@@ -363,10 +373,10 @@ static CameraK to_device_camera(const picp_camera* cam) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-static int grid_for(const picp_ctx* ctx, int64_t M, int per_thread) {
-    const int64_t want = (M + (int64_t)NT * per_thread - 1) / ((int64_t)NT * per_thread);
+static int grid_for(int64_t items, int threads, int max_blocks) {
+    const int64_t want = (items + threads - 1) / threads;
     int64_t g = want < 1 ? 1 : want;
-    if (g > ctx->max_blocks) g = ctx->max_blocks;
+    if (g > max_blocks) g = max_blocks;
     return (int)g;
 }
 
@@ -408,7 +418,7 @@ int picp_stage1(picp_ctx* ctx, const double* u, const double* v, const double* x
     DeviceGuard g(ctx->device);
     const CameraK c = to_device_camera(cam);
     const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
-    const int grid = grid_for(ctx, vec ? (M + 1) / 2 : M, 1);
+    const int grid = grid_for(vec ? (M + 1) / 2 : M, NT, ctx->max_blocks1);
     ctx->rows1 = grid;
     auto kern = vec ? (is_pinhole(cam->K) ? stage1_kernel<2, true> : stage1_kernel<2, false>)
                     : (is_pinhole(cam->K) ? stage1_kernel<1, true> : stage1_kernel<1, false>);
@@ -433,13 +443,13 @@ int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x
     DeviceGuard g(ctx->device);
     const CameraK c = to_device_camera(cam);
     const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
-    const int grid = grid_for(ctx, vec ? (M + 1) / 2 : M, 1);
+    const int grid = grid_for(vec ? (M + 1) / 2 : M, NT2, ctx->max_blocks2);
     ctx->rows2 = grid;
     const double* s1p = s1 ? s1 : ctx->part1;
     const int s1rows = s1 ? 1 : ctx->rows1;
     auto kern = vec ? (is_pinhole(cam->K) ? stage2_kernel<2, true> : stage2_kernel<2, false>)
                     : (is_pinhole(cam->K) ? stage2_kernel<1, true> : stage2_kernel<1, false>);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p, s1rows,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p, s1rows,
                        ctx->part2);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;

@@ -17,7 +17,8 @@ def _row(vals):
 
 
 def write_data_dir(directory, frames=121):
-    b = load()
+    npz = load()
+    b = {k: npz[k] for k in npz.files}      # NpzFile decompresses on every [] access
     os.makedirs(directory, exist_ok=True)
     K, C = b["camera_matrix"], b["cam_transform"]
     with open(os.path.join(directory, "camera.dat"), "w") as fh:
