@@ -91,6 +91,25 @@ def time_stage2(ctx, pkg, corr, cam, sched, reps=40):
     return float(ms.mean()), float(ms.min())
 
 
+def pmc_traffic(M, world):
+    """HBM bytes per stage-2 launch from the committed rocprofv3 counter passes (FETCH_SIZE and
+    WRITE_SIZE, separate runs of this same command; profiles/summarize.py applies the gfx950
+    corrections).  Counters cannot be read from inside the process, so the figure is only reported
+    for the workload it was collected on."""
+    import glob
+    if world != 1 or M != (1 << 20):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_2p20.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        k = json.load(fh)["kernels"]
+    for name, v in k.items():
+        if "stage2_kernel" in name:
+            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(M, iterations):
     """The numpy restatement of the loop on the host: one process, numpy element-wise kernels
     (single core), on the first `iterations` iterations of the same M-correspondence problem."""
@@ -165,6 +184,7 @@ def main():
     if rank == 0:
         n_local = hi - lo
         achieved = BYTES_PER_CORR_PER_SCAN * n_local / (s2_mean_ms * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(M, world)
         out = {
             "metric": "ICP correspondence-iterations/sec",
             "value": M * ITERATIONS * args.steps / dt,
@@ -182,7 +202,7 @@ def main():
                        "correspondences": M, "lm_iterations": ITERATIONS,
                        "final_pose_error": float(np.max(np.abs(np.array(list(res.T)).reshape(4, 4) - true_pose())))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "stage2_kernel (linearise + H/b reduction)",
                          "bytes_per_launch": BYTES_PER_CORR_PER_SCAN * n_local,
                          "mean_launch_ms": s2_mean_ms, "min_launch_ms": s2_min_ms,
