@@ -128,6 +128,9 @@ def cpu_baseline(M, iterations):
 
 def main():
     args = parse()
+    if os.environ.get("PICP_BENCH_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PICP_BENCH_DEBUG"]), exit=True)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,10 +140,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Rehearsal knobs for a box with a single GPU (the real multi-GPU run uses neither): all ranks on
+    # device 0 and gloo for the two small all-reduces, since RCCL refuses two ranks on one device.
+    backend = os.environ.get("PICP_BENCH_BACKEND", "nccl")
+    if os.environ.get("PICP_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     from tests.synthetic import true_pose
     pkg = importlib.import_module("monocular-visual-odometry_amd")
     L = pkg._lib

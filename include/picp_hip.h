@@ -43,7 +43,7 @@ extern "C" {
 #define PICP_STATE_DOUBLES 96
 /* Doubles in the stage-1 / stage-2 reduction records (the all-reduce payloads when sharded). */
 #define PICP_S1_DOUBLES 4
-#define PICP_S2_DOUBLES 64
+#define PICP_S2_DOUBLES 32
 
 /* History row layout (doubles).  Rows 0..19 are the reference's five per-iteration lists
  * (src/ProjectiveICP.py:173, :233-237); the rest is recorded for parity checks. */

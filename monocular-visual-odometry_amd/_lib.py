@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpicp_hip.so")
 HIST_STRIDE = 80
 STATE_DOUBLES = 96
 S1_DOUBLES = 4
-S2_DOUBLES = 64
+S2_DOUBLES = 32
 
 # history row layout (include/picp_hip.h)
 H_T, H_ERROR, H_NUM_INLIERS, H_KERNEL_THR, H_DAMPING = 0, 16, 17, 18, 19

@@ -51,10 +51,10 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     ctx->num_cus = prop.multiProcessorCount;
     // Stage 1: two 256-thread workgroups per CU (measured: four per CU is slower at 2^20
     // correspondences, the extra waves only lengthen the launch ramp and the partial fold).
-    // Stage 2 keeps ~110 accumulator registers per lane, which leaves room for two waves per
-    // SIMD: one 512-thread workgroup per CU.
+    // Stage 2 keeps 58 accumulator registers per lane and fits 128 registers in all, i.e. four waves
+    // per SIMD: two 512-thread workgroups per CU.
     ctx->max_blocks1 = 2 * ctx->num_cus;
-    ctx->max_blocks2 = ctx->num_cus;
+    ctx->max_blocks2 = 2 * ctx->num_cus;
     hipError_t e = hipMalloc(&ctx->part1, sizeof(double) * PICP_S1_DOUBLES * ctx->max_blocks1);
     if (e == hipSuccess) e = hipMalloc(&ctx->part2, sizeof(double) * PICP_S2_DOUBLES * ctx->max_blocks2);
     if (e == hipSuccess) e = hipMalloc(&ctx->scratch, sizeof(double) * SCR_DOUBLES);

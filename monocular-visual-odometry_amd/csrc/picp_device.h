@@ -30,25 +30,28 @@ enum : int {
     ST_RING = 41,        // [10] error_slope_ring_buffer
     ST_BEST_ERR = 51,    // running minimum of the error list (first minimum wins, :249)
     ST_BEST_IT = 52,     // its index
+    ST_MODE = 53,        // 0: stage 2 sums the mean-filtered set; 1: it re-sums the stage-1 set (see S2_*)
+    ST_N_STAGE2 = 54,    // mean-filter survivors found before a switch to mode 1 (for the history row)
     ST_BEST_T = 64,      // [16] pose of that iteration (:254)
     ST_START_T = 80,     // [16] pose on entry, returned when the result is invalid (:251)
 };
 
 // stage-1 record
 enum : int { S1_SUM_CHI = 0, S1_COUNT = 1, S1_N_INSIDE = 2, S1_PAD = 3 };
-// stage-2 record: sums over two candidate inlier sets,
-//   F = {chi <= threshold and chi < mean}        (the stage-2 set, src/ProjectiveICP.py:302)
-//   A = {chi <= threshold}                       (the stage-1 set, :294)
-// The reference uses F when it has >= min_inliers members, else A (:307-310).  A's chi sum and
-// member count are the stage-1 record's, so only F carries them here.
+// stage-2 record: H, b, sum of chi and member count of ONE candidate inlier set.
+//   mode 0: F = {chi <= threshold and chi < mean}   (the stage-2 set, src/ProjectiveICP.py:302)
+//   mode 1: A = {chi <= threshold}                  (the stage-1 set, :294)
+// The reference uses F when it has >= min_inliers members, else A (:307-310).  F almost always
+// qualifies, so the scan sums only F; when the solve step finds F too small it sets the state's
+// mode flag and does not advance, and the next round of stage launches re-sums A for the same pose.
+// (Summing both sets in every scan costs 40 more fused multiply-adds per correspondence and twice
+// the accumulator registers, for a result that is used only in degenerate iterations.)
 enum : int {
-    S2_HF = 0,    // [21] upper triangle of sum J^T J over F, row-major (00,01,..,05,11,..,55)
-    S2_BF = 21,   // [6]  sum J^T e over F
-    S2_CHI_F = 27,
-    S2_N_F = 28,
-    S2_HA = 29,   // [21] same over A
-    S2_BA = 50,   // [6]
-    S2_USED = 56, // number of meaningful entries; the record is padded to PICP_S2_DOUBLES
+    S2_H = 0,    // [21] upper triangle of sum J^T J, row-major (00,01,..,05,11,..,55)
+    S2_B = 21,   // [6]  sum J^T e
+    S2_CHI = 27, // sum of chi over the set
+    S2_N = 28,   // members
+    S2_USED = 29, // number of meaningful entries; the record is padded to PICP_S2_DOUBLES
 };
 
 struct CameraK {
@@ -231,22 +234,34 @@ __device__ __forceinline__ double dpp_move(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// Column sums of a 64 x 64 matrix held one row per lane: v[j] of lane l is element (l, j); on
-// return lane l holds sum over all lanes of v[l].  Six halving steps: at the step for lane-id bit
-// b a lane keeps the half of its values that its own bit selects and receives the partner
-// lane's partial sums of that same half, so the work halves every step (about 250
-// instructions for 64 values instead of 64 full butterflies).  Bits 5 and 4 use the gfx950 lane
-// swaps (v_permlane32_swap / v_permlane16_swap), bits 3..0 DPP row_mirror, row_half_mirror and
-// quad permutes, all of which pair a lane with one whose bit b differs and whose higher bits agree.
+// Column sums of a 64 x N matrix held one row per lane (N = 32 or 64): v[j] of lane l is element
+// (l, j); on return lane l (l < N) holds the sum over all 64 lanes of v[l].  Halving steps: at the
+// step for lane-id bit b a lane keeps the half of its values that its own bit selects and receives
+// the partner lane's partial sums of that same half, so the work halves every step (about 250
+// instructions instead of N full butterflies).  Bits 5 and 4 use the gfx950 lane swaps
+// (v_permlane32_swap / v_permlane16_swap), bits 3..0 DPP row_mirror, row_half_mirror and quad
+// permutes, all of which pair a lane with one whose bit b differs and whose higher bits agree.
+// With N = 32 the bit-5 step is a plain pairwise add (both halves keep all 32 sums).
 // The order of additions is fixed, so the result is reproducible.
-__device__ __forceinline__ double wave_column_sums(double (&v)[64]) {
+template <int N>
+__device__ __forceinline__ double wave_column_sums(double (&v)[N]) {
+    static_assert(N == 32 || N == 64, "32 or 64 values per lane");
     const int lane = threadIdx.x & 63;
     // bit 5
+    if (N == 64) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const u32x2_t lo = __builtin_amdgcn_permlane32_swap(__double2loint(v[i]), __double2loint(v[i + 32]), false, false);
-        const u32x2_t hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v[i]), __double2hiint(v[i + 32]), false, false);
-        v[i] = __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+        for (int i = 0; i < 32; ++i) {
+            const u32x2_t lo = __builtin_amdgcn_permlane32_swap(__double2loint(v[i]), __double2loint(v[(i + 32) % N]), false, false);
+            const u32x2_t hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v[i]), __double2hiint(v[(i + 32) % N]), false, false);
+            v[i] = __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const u32x2_t lo = __builtin_amdgcn_permlane32_swap(__double2loint(v[i]), __double2loint(v[i]), false, false);
+            const u32x2_t hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v[i]), __double2hiint(v[i]), false, false);
+            v[i] = __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+        }
     }
     // bit 4
 #pragma unroll
@@ -306,10 +321,13 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
     const int wave = threadIdx.x >> 6;
     double out = 0.0;
     if (NV > 8) {
-        double v[64];
+        // With 32 values the lane -> value map of wave_column_sums is lane % 32 for both halves.
+        constexpr int N = (NV <= 32) ? 32 : 64;
+        double v[N];
 #pragma unroll
-        for (int i = 0; i < 64; ++i) v[i] = (i < NV) ? vals[i] : 0.0;
-        lds[wave * 64 + lane] = wave_column_sums(v);
+        for (int i = 0; i < N; ++i) v[i] = (i < NV) ? vals[i] : 0.0;
+        const double tot = wave_column_sums<N>(v);
+        if (lane < N) lds[wave * 64 + lane] = tot;
         __syncthreads();
         if (threadIdx.x < NV) {
 #pragma unroll
@@ -556,10 +574,19 @@ struct StepRecord {
 // state update and history row (:231-238).
 // st: the state block (read and written).  s1/s2: the reduced stage records.
 // hist_row: this iteration's history row or nullptr.
-__device__ inline void solve_and_schedule(double* st, const double* s1, const double* s2, const picp_schedule& sc,
+// Returns false when the iteration could not be completed because the stage-2 record holds the
+// mean-filtered set F and F has fewer than min_inliers members: the state's mode flag is then set
+// and nothing else changes; the caller runs the stages again (stage 2 then sums the stage-1 set).
+__device__ inline bool solve_and_schedule(double* st, const double* s1, const double* s2, const picp_schedule& sc,
                                           double* hist_row) {
     const double n_inside = s1[S1_N_INSIDE];
     const double n1 = s1[S1_COUNT];
+    const bool redo_mode = (st[ST_MODE] != 0.0);
+    if (n_inside != 0.0 && n1 != 0.0 && !redo_mode && s2[S2_N] < (double)sc.min_inliers) { // :307
+        st[ST_MODE] = 1.0;
+        st[ST_N_STAGE2] = s2[S2_N];
+        return false;
+    }
     StepRecord r;
 #pragma unroll
     for (int i = 0; i < 36; ++i) r.H[i] = 0.0;
@@ -590,38 +617,31 @@ __device__ inline void solve_and_schedule(double* st, const double* s1, const do
             r.error = d_inf();
         } else {
             r.mean_stage1 = s1[S1_SUM_CHI] / n1;
-            const double nf = s2[S2_N_F];
-            r.n_stage2 = nf;
-            const bool use_f = (nf >= (double)sc.min_inliers); // :307
-            r.used_stage2 = use_f ? 1.0 : 0.0;
-            double chi_sum;
+            r.used_stage2 = redo_mode ? 0.0 : 1.0;
+            // in redo mode the number of mean-filter survivors was kept in the state block
+            r.n_stage2 = redo_mode ? st[ST_N_STAGE2] : s2[S2_N];
             int k = 0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
 #pragma unroll
                 for (int j = i; j < 6; ++j) {
-                    const double h = use_f ? s2[S2_HF + k] : s2[S2_HA + k];
+                    const double h = s2[S2_H + k];
                     r.H[i * 6 + j] = h;
                     r.H[j * 6 + i] = h;
                     ++k;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) r.b[i] = use_f ? s2[S2_BF + i] : s2[S2_BA + i];
-            if (use_f) {
-                r.n_inliers = nf;
-                chi_sum = s2[S2_CHI_F];
-            } else {
-                r.n_inliers = n1;
-                chi_sum = s1[S1_SUM_CHI];
-            }
-            r.error = (r.n_inliers > 0.0) ? chi_sum / r.n_inliers : d_inf(); // :319-321
+            for (int i = 0; i < 6; ++i) r.b[i] = s2[S2_B + i];
+            r.n_inliers = s2[S2_N];
+            r.error = (r.n_inliers > 0.0) ? s2[S2_CHI] / r.n_inliers : d_inf(); // :319-321
         }
         damped_solve6(r.H, r.b, lambda, r.dx); // :269-270
         double dT[16];
         v2T_device(r.dx, dT);
         matmul4(st + ST_W_T_C, dT, T1); // :271
     }
+    st[ST_MODE] = 0.0;
 
     // kernel threshold schedule (:200-205)
     if (r.n_inliers == n_inside) {
@@ -717,6 +737,7 @@ __device__ inline void solve_and_schedule(double* st, const double* s1, const do
         for (int i = 0; i < 36; ++i) hist_row[PICP_H_H + i] = r.H[i];
         for (int i = PICP_H_H + 36; i < PICP_HIST_STRIDE; ++i) hist_row[i] = 0.0;
     }
+    return true;
 }
 
 // Loop entry (src/ProjectiveICP.py:157-171): pose, camera state, base threshold and damping,

@@ -15,8 +15,8 @@
 namespace picp {
 
 constexpr int NT = 256;  // threads per workgroup of the stage-1 scan, the batched kernel and the small kernels
-constexpr int NT2 = 512; // stage-2 scan: one workgroup of eight waves per CU (its ~176 registers per lane allow two
-                         // waves per SIMD), so a launch leaves at most one partial record per CU to fold
+constexpr int NT2 = 512; // stage-2 scan: workgroups of eight waves, two per CU (128 registers per lane = four waves
+                         // per SIMD), so a launch leaves at most two partial records per CU to fold
 
 struct Pose16 {
     double m[16];
@@ -130,43 +130,42 @@ __global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u
 
 // ---- stage 2 --------------------------------------------------------------------------------
 struct Stage2Sums {
-    SetSums F, A;
-    double chi_f;
-    unsigned n_f;
+    SetSums S;
+    double chi;
+    unsigned n;
+    __device__ __forceinline__ void clear() {
+        S.clear();
+        chi = 0.0;
+        n = 0u;
+    }
 };
 
+// `all` = the state's mode flag: false sums the mean-filtered set (chi < mean, strict,
+// src/ProjectiveICP.py:302), true the whole stage-1 set.
 template <bool PINHOLE>
 __device__ __forceinline__ void stage2_point(const double* __restrict__ T, const CameraK& cam, double thr, double mean,
-                                             double mu, double mv, double x, double y, double z, Stage2Sums& s) {
+                                             bool all, double mu, double mv, double x, double y, double z,
+                                             Stage2Sums& s) {
     const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
     const double e0 = mu - p.u, e1 = mv - p.v;
     const double chi = e0 * e0 + e1 * e1;
-    const bool keep = p.inside && (chi <= thr);
+    const bool keep = p.inside && (chi <= thr) && (all || chi < mean);
     if (keep) {
         double J0[6], J1[6];
         jacobian_rows<PINHOLE>(p, cam, J0, J1);
-        s.A.add<PINHOLE>(J0, J1, e0, e1);
-        if (chi < mean) { // src/ProjectiveICP.py:302 (strict)
-            s.F.add<PINHOLE>(J0, J1, e0, e1);
-            s.chi_f += chi;
-            s.n_f += 1u;
-        }
+        s.S.add<PINHOLE>(J0, J1, e0, e1);
+        s.chi += chi;
+        s.n += 1u;
     }
 }
 
 __device__ __forceinline__ void pack_sets(const Stage2Sums& s, double (&vals)[S2_USED]) {
 #pragma unroll
-    for (int i = 0; i < 21; ++i) {
-        vals[S2_HF + i] = s.F.H[i];
-        vals[S2_HA + i] = s.A.H[i];
-    }
+    for (int i = 0; i < 21; ++i) vals[S2_H + i] = s.S.H[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        vals[S2_BF + i] = s.F.b[i];
-        vals[S2_BA + i] = s.A.b[i];
-    }
-    vals[S2_CHI_F] = s.chi_f;
-    vals[S2_N_F] = (double)s.n_f;
+    for (int i = 0; i < 6; ++i) vals[S2_B + i] = s.S.b[i];
+    vals[S2_CHI] = s.chi;
+    vals[S2_N] = (double)s.n;
 }
 
 template <int VEC, bool PINHOLE>
@@ -195,13 +194,11 @@ __global__ __launch_bounds__(NT2) void stage2_kernel(const double* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = state[ST_C_T_W + i];
     const double thr = state[ST_THR];
+    const bool all = (state[ST_MODE] != 0.0);
     Stage2Sums s;
-    s.F.clear();
-    s.A.clear();
-    s.chi_f = 0.0;
-    s.n_f = 0u;
+    s.clear();
     for_each_correspondence<VEC, NT2>(u, v, x, y, z, M, [&](double mu, double mv, double px, double py, double pz) {
-        stage2_point<PINHOLE>(T, cam, thr, mean, mu, mv, px, py, pz, s);
+        stage2_point<PINHOLE>(T, cam, thr, mean, all, mu, mv, px, py, pz, s);
     });
     double vals[S2_USED];
     pack_sets(s, vals);
@@ -248,12 +245,14 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
     __shared__ double row[PICP_HIST_STRIDE];
     if (threadIdx.x < PICP_STATE_DOUBLES) st[threadIdx.x] = state[threadIdx.x];
     __syncthreads();
+    __shared__ int advanced;
     const int it = (int)st[ST_IT];
     const bool record = (hist != nullptr && it < hist_rows);
-    if (threadIdx.x == 0) solve_and_schedule(st, s1, s2, sc, record ? row : nullptr);
+    if (threadIdx.x == 0) advanced = solve_and_schedule(st, s1, s2, sc, record ? row : nullptr) ? 1 : 0;
     __syncthreads();
     if (threadIdx.x < PICP_STATE_DOUBLES) state[threadIdx.x] = st[threadIdx.x];
-    if (record && threadIdx.x < PICP_HIST_STRIDE) hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
+    if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
+        hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
 }
 
 // ---- whole loop in one workgroup, one problem per workgroup -------------------------------------
@@ -313,34 +312,38 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
             __syncthreads();
         }
         const double n1 = s1[S1_COUNT];
-        if (n1 != 0.0) {
-            const double mean = s1[S1_SUM_CHI] / n1;
-            Stage2Sums s;
-            s.F.clear();
-            s.A.clear();
-            s.chi_f = 0.0;
-            s.n_f = 0u;
-            if (R > 0) {
+        // Stage 2 sums the mean-filtered set; if the solve step finds it too small (block-uniform,
+        // rare) the scan is repeated over the whole stage-1 set for the same pose.
+        for (int pass = 0; pass < 2; ++pass) {
+            if (n1 != 0.0) {
+                const double mean = s1[S1_SUM_CHI] / n1;
+                const bool all = (st[ST_MODE] != 0.0);
+                Stage2Sums s;
+                s.clear();
+                if (R > 0) {
 #pragma unroll
-                for (int r = 0; r < RR; ++r)
-                    if (r * NT + (int)threadIdx.x < cnt)
-                        stage2_point<PINHOLE>(T, cam, thr, mean, ru[r], rv[r], rx[r], ry[r], rz[r], s);
-            } else {
-                for (int i = threadIdx.x; i < cnt; i += NT)
-                    stage2_point<PINHOLE>(T, cam, thr, mean, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], s);
+                    for (int r = 0; r < RR; ++r)
+                        if (r * NT + (int)threadIdx.x < cnt)
+                            stage2_point<PINHOLE>(T, cam, thr, mean, all, ru[r], rv[r], rx[r], ry[r], rz[r], s);
+                } else {
+                    for (int i = threadIdx.x; i < cnt; i += NT)
+                        stage2_point<PINHOLE>(T, cam, thr, mean, all, u[beg + i], v[beg + i], x[beg + i], y[beg + i],
+                                              z[beg + i], s);
+                }
+                double vals[S2_USED];
+                pack_sets(s, vals);
+                const double tot = block_sum<S2_USED, NT>(vals, lds);
+                if (threadIdx.x < S2_USED) s2[threadIdx.x] = tot;
+                __syncthreads();
             }
-            double vals[S2_USED];
-            pack_sets(s, vals);
-            const double tot = block_sum<S2_USED, NT>(vals, lds);
-            if (threadIdx.x < S2_USED) s2[threadIdx.x] = tot;
+            if (threadIdx.x == 0) {
+                const int it = (int)st[ST_IT];
+                double* row = (myhist != nullptr && it < hist_rows) ? myhist + (size_t)it * PICP_HIST_STRIDE : nullptr;
+                solve_and_schedule(st, s1, s2, sc, row);
+            }
             __syncthreads();
+            if (st[ST_MODE] == 0.0) break;
         }
-        if (threadIdx.x == 0) {
-            const int it = (int)st[ST_IT];
-            double* row = (myhist != nullptr && it < hist_rows) ? myhist + (size_t)it * PICP_HIST_STRIDE : nullptr;
-            solve_and_schedule(st, s1, s2, sc, row);
-        }
-        __syncthreads();
     }
     if (threadIdx.x == 0) {
         picp_result r;
@@ -509,27 +512,31 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
                  "picp_run: history has %d rows, num_iterations is %d", hist_rows, sched->num_iterations);
     if (int rc = picp_state_init(ctx, state, w_T_c0_host, sched)) return rc;
     DeviceGuard g(ctx->device);
-    // Iterations are enqueued in chunks; between chunks the stop flag is read back so that a loop
-    // that converged after a few iterations does not pay for launches that would do nothing.
-    // Every kernel also returns at once when the flag is set, so a chunk may overshoot safely.
+    // Rounds of {stage 1, stage 2, solve} are enqueued in chunks; between chunks the stop flag is
+    // read back, so a loop that converged after a few iterations does not pay for launches that
+    // would do nothing (every kernel returns at once when the flag is set, so overshooting is
+    // safe).  A round normally completes one iteration; in the rare case that the mean-filtered
+    // set is too small it only switches stage 2 to the stage-1 set and the next round completes
+    // the iteration, so at most 2 * num_iterations rounds are ever needed.  The stop flag is set
+    // by the solve step when the stop test fires or num_iterations is reached.
     const int total = sched->num_iterations;
     int chunk = sched->disable_stop ? total : 8;
     int issued = 0;
-    while (issued < total) {
-        const int n = (total - issued < chunk) ? (total - issued) : chunk;
+    while (total > 0 && issued < 2 * total) {
+        const int n = chunk < 1 ? 1 : chunk;
         for (int k = 0; k < n; ++k) {
             if (int rc = picp_stage1(ctx, u, v, x, y, z, M, state, cam)) return rc;
             if (int rc = picp_stage2(ctx, u, v, x, y, z, M, state, cam, nullptr)) return rc;
             if (int rc = picp_solve(ctx, state, sched, nullptr, nullptr, hist, hist_rows)) return rc;
         }
         issued += n;
-        if (issued < total) {
-            double* h = ctx->pinned;
-            PICP_HIP_CHECK(hipMemcpyAsync(h, state + ST_STOP, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            if (h[0] != 0.0) break;
-            if (chunk < 64) chunk *= 2;
-        }
+        double* h = ctx->pinned;
+        PICP_HIP_CHECK(hipMemcpyAsync(h, state + ST_IT, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (h[1] != 0.0) break; // ST_STOP follows ST_IT
+        const int left = total - (int)h[0];
+        chunk = sched->disable_stop ? left : (chunk < 64 ? chunk * 2 : chunk);
+        if (chunk > left) chunk = left;
     }
     return picp_finish(ctx, state, hist, hist_rows, w_T_c0_host, result);
 }
@@ -571,35 +578,40 @@ int picp_linearize(picp_ctx* ctx, const double* u, const double* v, const double
     PICP_HIP_CHECK(hipMemsetAsync(s2, 0, PICP_S2_DOUBLES * sizeof(double), ctx->stream));
     if (int rc = picp_stage1(ctx, u, v, x, y, z, M, state, cam)) return rc;
     if (int rc = picp_stage1_reduce(ctx, s1)) return rc;
-    if (int rc = picp_stage2(ctx, u, v, x, y, z, M, state, cam, s1)) return rc;
-    if (int rc = picp_stage2_reduce(ctx, s2)) return rc;
     double* h = ctx->pinned;
-    PICP_HIP_CHECK(hipMemcpyAsync(h, s1, (SCR_S2 - SCR_S1 + PICP_S2_DOUBLES) * sizeof(double), hipMemcpyDeviceToHost,
-                                  ctx->stream));
-    PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const double* hs1 = h;
     const double* hs2 = h + (SCR_S2 - SCR_S1);
     for (int i = 0; i < 36; ++i) H[i] = 0.0;
     for (int i = 0; i < 6; ++i) b[i] = 0.0;
-    if (n_inside) *n_inside = (int64_t)hs1[S1_N_INSIDE];
-    if (hs1[S1_COUNT] == 0.0) { // src/ProjectiveICP.py:300
-        *num_inliers = 0;
-        *error = __builtin_inf();
-        return PICP_OK;
+    // mode 0 sums the mean-filtered set; if it has fewer than min_inliers members the scan is
+    // repeated in mode 1 over the stage-1 set (src/ProjectiveICP.py:307-310)
+    for (int mode = 0; mode < 2; ++mode) {
+        if (mode == 1) {
+            const double one = 1.0;
+            PICP_HIP_CHECK(hipMemcpyAsync(state + ST_MODE, &one, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (int rc = picp_stage2(ctx, u, v, x, y, z, M, state, cam, s1)) return rc;
+        if (int rc = picp_stage2_reduce(ctx, s2)) return rc;
+        PICP_HIP_CHECK(hipMemcpyAsync(h, s1, (SCR_S2 - SCR_S1 + PICP_S2_DOUBLES) * sizeof(double),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+        PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (n_inside) *n_inside = (int64_t)hs1[S1_N_INSIDE];
+        if (hs1[S1_COUNT] == 0.0) { // :300
+            *num_inliers = 0;
+            *error = __builtin_inf();
+            return PICP_OK;
+        }
+        if (mode == 1 || hs2[S2_N] >= (double)min_inliers) break;
     }
-    const bool use_f = hs2[S2_N_F] >= (double)min_inliers; // :307
     int k = 0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j, ++k) {
-            const double hv = use_f ? hs2[S2_HF + k] : hs2[S2_HA + k];
-            H[i * 6 + j] = hv;
-            H[j * 6 + i] = hv;
+            H[i * 6 + j] = hs2[S2_H + k];
+            H[j * 6 + i] = hs2[S2_H + k];
         }
-    for (int i = 0; i < 6; ++i) b[i] = use_f ? hs2[S2_BF + i] : hs2[S2_BA + i];
-    const double n = use_f ? hs2[S2_N_F] : hs1[S1_COUNT];
-    const double chi = use_f ? hs2[S2_CHI_F] : hs1[S1_SUM_CHI];
-    *num_inliers = (int64_t)n;
-    *error = n > 0.0 ? chi / n : __builtin_inf();
+    for (int i = 0; i < 6; ++i) b[i] = hs2[S2_B + i];
+    *num_inliers = (int64_t)hs2[S2_N];
+    *error = hs2[S2_N] > 0.0 ? hs2[S2_CHI] / hs2[S2_N] : __builtin_inf();
     return PICP_OK;
 }
 

@@ -4,7 +4,7 @@ Every rank (one process per GPU) holds a contiguous slice of the five correspond
 replica of the loop state.  One iteration is
 
     stage 1 scan (local)  ->  all-reduce of {sum chi, count, in-image count}      (4 doubles)
-    stage 2 scan (local)  ->  all-reduce of both candidate sets' H, b, chi, count (64 doubles)
+    stage 2 scan (local)  ->  all-reduce of the inlier set's H, b, sum chi, count (32 doubles)
     solve + schedules (replicated: identical inputs give identical state on every rank)
 
 The two exchanges are `torch.distributed.all_reduce` calls (RCCL over xGMI with the "nccl"
@@ -78,25 +78,52 @@ class HipStages:
         return res, hist
 
 
-def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=False):
+def _all_reduce_sum(t, group, through_host):
+    import torch.distributed as dist
+    if through_host and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=False, through_host=None):
     """Drives ``stages`` (this rank's shard) through the loop with the two all-reduces per iteration.
 
     ``stages`` provides state_init / stage1 / stage2 / solve / stopped / finish (see HipStages).
     With ``group`` None and no initialised process group the exchanges are skipped (one shard).
-    The stop flag is identical on all ranks, so every rank leaves the loop at the same iteration;
-    it is read back every ``check_every`` iterations (a host synchronisation), never when
-    ``disable_stop`` is set."""
+
+    A round is stage 1 -> all-reduce -> stage 2 -> all-reduce -> solve.  It normally completes one
+    iteration; when the mean-filtered inlier set turns out too small the solve step only switches
+    stage 2 to the stage-1 set and the next round completes the iteration.  The loop therefore runs
+    until the replicated state's stop flag is set (stop test fired, or num_iterations completed),
+    reading the flag back -- a host synchronisation -- every ``check_every`` rounds, or only after
+    num_iterations rounds when ``disable_stop`` is set.  The flag is identical on all ranks, so every
+    rank leaves the loop after the same round.
+
+    ``through_host``: stage the two records through host memory for the all-reduce.  Default: only
+    when the process group's backend is not "nccl" (RCCL reduces device buffers in place; the gloo
+    backend is a CPU transport and is used for rehearsals on machines without one GPU per rank)."""
     import torch.distributed as dist
     exchange = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if through_host is None:
+        through_host = exchange and dist.get_backend(group) != "nccl"
     stages.state_init()
-    for it in range(int(num_iterations)):
+    total = int(num_iterations)
+    rounds = 0
+    next_check = total if disable_stop else min(check_every, total)
+    while total > 0 and rounds < 2 * total:
         s1 = stages.stage1()
         if exchange:
-            dist.all_reduce(s1, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce_sum(s1, group, through_host)
         s2 = stages.stage2(s1)
         if exchange:
-            dist.all_reduce(s2, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce_sum(s2, group, through_host)
         stages.solve(s1, s2)
-        if not disable_stop and (it + 1) % check_every == 0 and it + 1 < num_iterations and stages.stopped():
-            break
+        rounds += 1
+        if rounds >= next_check:
+            if stages.stopped():
+                break
+            next_check = rounds + (1 if disable_stop else check_every)
     return stages.finish()

@@ -8,7 +8,9 @@ compared with the monolithic restatement in picp_oracle.projective_icp.
 
 Record layouts are the device's (csrc/picp_device.h):
   s1 = [sum chi, count, in-image count, 0]                       over chi <= kernel_threshold
-  s2 = [HF(21), bF(6), sum chi F, count F, HA(21), bA(6), 0...]  F = stage-1 set with chi < mean, A = stage-1 set
+  s2 = [H(21), b(6), sum chi, count, 0, 0, 0]  of ONE set: the stage-1 set with chi < mean (mode 0) or
+       the whole stage-1 set (mode 1, entered when the solve step finds the mode-0 set smaller than
+       min_inliers; that round does not advance the iteration)
 """
 from __future__ import annotations
 
@@ -34,6 +36,7 @@ class NumpyStages:
         self.error_prev, self.ring = np.inf, np.zeros(10)
         self.mean_slope = self.sigma_slope = 0.0
         self.stuck = self.flicker = self.it = 0
+        self.mode = 0
         self.stop = self.p.num_iterations <= 0
         self.hist = {"T": [], "error": [], "num_inliers": [], "kernel_threshold": [], "dumping_factor": [],
                      "n_inside": []}
@@ -53,17 +56,15 @@ class NumpyStages:
         return torch.tensor([chi[keep].sum(), keep.sum(), inside.sum(), 0.0], dtype=torch.float64)
 
     def stage2(self, s1):
-        out = np.zeros(64)
+        out = np.zeros(32)
         if self.stop or float(s1[1]) == 0.0:
             return torch.from_numpy(out)
         e, J, chi, keep = self._cache
         mean = float(s1[0]) / float(s1[1])
-        f = keep & (chi < mean)
-        for base, m in ((0, f), (29, keep)):
-            H = np.einsum("mri,mrj->ij", J[m], J[m])
-            out[base:base + 21] = H[IU]
-            out[base + 21:base + 27] = np.einsum("mri,mr->i", J[m], e[m])
-        out[27], out[28] = chi[f].sum(), f.sum()
+        m = keep if self.mode else (keep & (chi < mean))
+        out[0:21] = np.einsum("mri,mrj->ij", J[m], J[m])[IU]
+        out[21:27] = np.einsum("mri,mr->i", J[m], e[m])
+        out[27], out[28] = chi[m].sum(), m.sum()
         return torch.from_numpy(out)
 
     def solve(self, s1, s2):                               # :260-273, :200-238
@@ -71,6 +72,10 @@ class NumpyStages:
             return
         s1, s2, p = s1.numpy(), s2.numpy(), self.p
         n_inside, n1 = s1[2], s1[1]
+        if n_inside != 0 and n1 != 0 and not self.mode and s2[28] < p.min_inliers:
+            self.mode = 1                                  # :307 failed: re-sum the stage-1 set, same pose
+            return
+        self.mode = 0
         if n_inside == 0:
             T1, n_inl, error, done = self.w_T_c, 0, np.inf, False
         else:
@@ -79,14 +84,11 @@ class NumpyStages:
             if n1 == 0:
                 n_inl, error = 0, np.inf
             else:
-                use_f = s2[28] >= p.min_inliers
-                base = 0 if use_f else 29
-                H[IU] = s2[base:base + 21]
+                H[IU] = s2[0:21]
                 H = H + np.triu(H, 1).T
-                b = s2[base + 21:base + 27]
-                n_inl = int(s2[28]) if use_f else int(n1)
-                chi_sum = s2[27] if use_f else s1[0]
-                error = chi_sum / n_inl if n_inl > 0 else np.inf
+                b = s2[21:27]
+                n_inl = int(s2[28])
+                error = s2[27] / n_inl if n_inl > 0 else np.inf
             dx = np.linalg.lstsq(H + np.eye(6) * self.lam, -b, rcond=None)[0]
             T1 = self.w_T_c @ po.v2T(dx)
         if n_inl == n_inside:
