@@ -349,43 +349,62 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
     return out;
 }
 
-// Folds `rows` partial records of NV doubles (row stride `stride`) into totals.  Every thread with
-// tid < NV of a workgroup of NT threads returns the total of column tid.  The workgroup is split
-// into NT/CW row groups of CW lanes (CW = NV rounded up to a power of two); a group adds its rows in
-// index order, then the groups are added in index order, so the result does not depend on
-// scheduling.  Loads are issued in independent batches of B: a one-load-per-iteration loop would
-// pay a full memory round trip per row.
+// Folds `rows` partial records of NV doubles (row stride `stride`) into totals, in two phases so
+// that several folds and other loads can be in flight together: issue() starts the loads of this
+// thread's first B rows, finish() adds them (and any further rows) and combines the threads.
+// The workgroup of NT threads is split into NT/CW row groups of CW lanes (CW = NV rounded up to a
+// power of two); a group adds its rows in index order, then the groups are combined in a fixed
+// two-level order, so the result does not depend on scheduling.  After finish() every thread with
+// tid < NV holds the total of column tid.  A one-load-per-iteration loop would pay a full memory
+// round trip per row; here a thread has B independent loads in flight.
 // lds: at least NT doubles.
-template <int NV, int NT, int B = 16>
-__device__ __forceinline__ double fold_partials(const double* __restrict__ part, int rows, int stride,
-                                                double* lds) {
-    constexpr int CW = NV <= 4 ? 4 : (NV <= 8 ? 8 : (NV <= 16 ? 16 : (NV <= 32 ? 32 : 64)));
-    static_assert(NV <= 64 && NT % CW == 0, "column per lane");
-    constexpr int G = NT / CW; // row groups
-    // B = loads in flight per thread
-    const int col = threadIdx.x % CW;
-    const int grp = threadIdx.x / CW;
-    double acc = 0.0;
-    if (col < NV) {
-        for (int r0 = grp; r0 < rows; r0 += G * B) {
-            double v[B];
+template <int NV, int NT, int B>
+struct PartialFold {
+    static constexpr int CW = NV <= 4 ? 4 : (NV <= 8 ? 8 : (NV <= 16 ? 16 : (NV <= 32 ? 32 : 64)));
+    static constexpr int G = NT / CW; // row groups
+    static_assert(NV <= 64 && NT % 64 == 0 && NT % CW == 0, "column per lane");
+    double v[B];
+    __device__ __forceinline__ void issue(const double* __restrict__ part, int rows, int stride) {
+        const int col = threadIdx.x % CW, grp = threadIdx.x / CW;
 #pragma unroll
-            for (int k = 0; k < B; ++k) {
-                const int r = r0 + k * G;
-                v[k] = (r < rows) ? part[(size_t)r * stride + col] : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < B; ++k) acc += v[k];
+        for (int k = 0; k < B; ++k) {
+            const int r = grp + k * G;
+            v[k] = (col < NV && r < rows) ? part[(size_t)r * stride + col] : 0.0;
         }
     }
-    lds[threadIdx.x] = acc;
-    __syncthreads();
-    double out = 0.0;
-    if (threadIdx.x < NV) {
-        for (int g = 0; g < G; ++g) out += lds[g * CW + threadIdx.x];
+    __device__ __forceinline__ double finish(const double* __restrict__ part, int rows, int stride, double* lds) {
+        const int col = threadIdx.x % CW, grp = threadIdx.x / CW;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < B; ++k) acc += v[k];
+        if (col < NV) {
+            for (int r = grp + B * G; r < rows; r += G) acc += part[(size_t)r * stride + col]; // more rows than B * G: rare
+        }
+        lds[threadIdx.x] = acc;
+        __syncthreads();
+        double a = 0.0;
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int k = 0; k < NT / 64; ++k) a += lds[threadIdx.x + 64 * k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) lds[threadIdx.x] = a;
+        __syncthreads();
+        double out = 0.0;
+        if (threadIdx.x < NV) {
+#pragma unroll
+            for (int g = 0; g < 64 / CW; ++g) out += lds[g * CW + threadIdx.x];
+        }
+        __syncthreads();
+        return out;
     }
-    __syncthreads();
-    return out;
+};
+
+template <int NV, int NT, int B = 16>
+__device__ __forceinline__ double fold_partials(const double* __restrict__ part, int rows, int stride, double* lds) {
+    PartialFold<NV, NT, B> f;
+    f.issue(part, rows, stride);
+    return f.finish(part, rows, stride, lds);
 }
 
 // ---- small dense routines used by the solve (one lane) ---------------------------------------

@@ -60,51 +60,65 @@ __device__ __forceinline__ Corr2 load2(const double2* __restrict__ u, const doub
     return c;
 }
 
-// Streams the correspondences through `point(mu, mv, x, y, z)`.  VEC == 2: 16-byte loads, the
-// loads of the next grid-stride step are issued before the current pair is processed, so a wave
-// always has a full step of HBM requests in flight while it computes.
-template <int VEC, int THREADS, typename F>
-__device__ __forceinline__ void for_each_correspondence(const double* __restrict__ u, const double* __restrict__ v,
-                                                        const double* __restrict__ x, const double* __restrict__ y,
-                                                        const double* __restrict__ z, int64_t M, F&& point) {
-    const int64_t stride = (int64_t)gridDim.x * THREADS;
-    const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (VEC == 2) {
-        const int64_t n2 = M >> 1;
-        const double2* u2 = reinterpret_cast<const double2*>(u);
-        const double2* v2 = reinterpret_cast<const double2*>(v);
-        const double2* x2 = reinterpret_cast<const double2*>(x);
-        const double2* y2 = reinterpret_cast<const double2*>(y);
-        const double2* z2 = reinterpret_cast<const double2*>(z);
-        // Two register sets in ping-pong: while set A is processed the loads of set B are in
-        // flight and vice versa, with no register copies between steps.  The prefetch is
-        // unconditional (past the end it re-reads the current step, a cache hit whose data is
-        // dropped): a load under a lane-dependent branch would make the compiler wait for every
-        // outstanding load at the join, the prefetched ones included.
-        int64_t i = tid;
-        if (i < n2) {
-            Corr2 A = load2(u2, v2, x2, y2, z2, i), B;
-            for (;;) {
-                const int64_t j = i + stride;
-                const bool hasB = j < n2;
-                B = load2(u2, v2, x2, y2, z2, hasB ? j : i);
-                point(A.u.x, A.v.x, A.x.x, A.y.x, A.z.x);
-                point(A.u.y, A.v.y, A.x.y, A.y.y, A.z.y);
-                if (!hasB) break;
-                const int64_t k = j + stride;
-                const bool hasA = k < n2;
-                A = load2(u2, v2, x2, y2, z2, hasA ? k : j);
-                point(B.u.x, B.v.x, B.x.x, B.y.x, B.z.x);
-                point(B.u.y, B.v.y, B.x.y, B.y.y, B.z.y);
-                if (!hasA) break;
-                i = k;
-            }
-        }
-        if ((M & 1) && tid == 0) point(u[M - 1], v[M - 1], x[M - 1], y[M - 1], z[M - 1]);
-    } else {
-        for (int64_t i = tid; i < M; i += stride) point(u[i], v[i], x[i], y[i], z[i]);
+// Streams a workgroup grid's share of the correspondences through `point(mu, mv, x, y, z)`.
+// VEC == 2: 16-byte loads; the loads of the next grid-stride step are issued before the current
+// pair of correspondences is processed, so a wave always has a full step of HBM requests in flight
+// while it computes.  start() issues the very first loads; kernels call it before their prologue
+// (state, partial records), because the addresses depend on nothing but the thread index.
+template <int VEC, int THREADS>
+struct CorrStream {
+    const double *u, *v, *x, *y, *z;
+    int64_t M, stride, tid;
+    Corr2 A;
+    __device__ __forceinline__ void start(const double* u_, const double* v_, const double* x_, const double* y_,
+                                          const double* z_, int64_t M_) {
+        u = u_, v = v_, x = x_, y = y_, z = z_, M = M_;
+        stride = (int64_t)gridDim.x * THREADS;
+        tid = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+        if (VEC == 2 && tid < (M >> 1))
+            A = load2(reinterpret_cast<const double2*>(u), reinterpret_cast<const double2*>(v),
+                      reinterpret_cast<const double2*>(x), reinterpret_cast<const double2*>(y),
+                      reinterpret_cast<const double2*>(z), tid);
     }
-}
+    template <typename F>
+    __device__ __forceinline__ void run(F&& point) {
+        if (VEC == 2) {
+            const int64_t n2 = M >> 1;
+            const double2* u2 = reinterpret_cast<const double2*>(u);
+            const double2* v2 = reinterpret_cast<const double2*>(v);
+            const double2* x2 = reinterpret_cast<const double2*>(x);
+            const double2* y2 = reinterpret_cast<const double2*>(y);
+            const double2* z2 = reinterpret_cast<const double2*>(z);
+            // Two register sets in ping-pong: while set A is processed the loads of set B are in
+            // flight and vice versa, with no register copies between steps.  The prefetch is
+            // unconditional (past the end it re-reads the current step, a cache hit whose data is
+            // dropped): a load under a lane-dependent branch would make the compiler wait for every
+            // outstanding load at the join, the prefetched ones included.
+            int64_t i = tid;
+            if (i < n2) {
+                Corr2 B;
+                for (;;) {
+                    const int64_t j = i + stride;
+                    const bool hasB = j < n2;
+                    B = load2(u2, v2, x2, y2, z2, hasB ? j : i);
+                    point(A.u.x, A.v.x, A.x.x, A.y.x, A.z.x);
+                    point(A.u.y, A.v.y, A.x.y, A.y.y, A.z.y);
+                    if (!hasB) break;
+                    const int64_t k = j + stride;
+                    const bool hasA = k < n2;
+                    A = load2(u2, v2, x2, y2, z2, hasA ? k : j);
+                    point(B.u.x, B.v.x, B.x.x, B.y.x, B.z.x);
+                    point(B.u.y, B.v.y, B.x.y, B.y.y, B.z.y);
+                    if (!hasA) break;
+                    i = k;
+                }
+            }
+            if ((M & 1) && tid == 0) point(u[M - 1], v[M - 1], x[M - 1], y[M - 1], z[M - 1]);
+        } else {
+            for (int64_t i = tid; i < M; i += stride) point(u[i], v[i], x[i], y[i], z[i]);
+        }
+    }
+};
 
 template <int VEC, bool PINHOLE>
 __global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u, const double* __restrict__ v,
@@ -113,13 +127,15 @@ __global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u
                                                     const double* __restrict__ state, CameraK cam,
                                                     double* __restrict__ part) {
     __shared__ double lds[(NT / 64) * 64];
+    CorrStream<VEC, NT> stream;
+    stream.start(u, v, x, y, z, M); // first loads in flight before the state block is read
     if (state[ST_STOP] != 0.0) return;
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = state[ST_C_T_W + i];
     const double thr = state[ST_THR];
     Stage1Sums s{0.0, 0u, 0u};
-    for_each_correspondence<VEC, NT>(u, v, x, y, z, M, [&](double mu, double mv, double px, double py, double pz) {
+    stream.run([&](double mu, double mv, double px, double py, double pz) {
         stage1_point<PINHOLE>(T, cam, thr, mu, mv, px, py, pz, s);
     });
     const double vals[3] = {s.sum_chi, (double)s.n1, (double)s.n_inside};
@@ -177,9 +193,14 @@ __global__ __launch_bounds__(NT2) void stage2_kernel(const double* __restrict__ 
                                                     double* __restrict__ part) {
     __shared__ double lds[(NT2 / 64) * 64];
     __shared__ double s1[PICP_S1_DOUBLES];
+    // first correspondences and the stage-1 records are requested together, before anything waits
+    CorrStream<VEC, NT2> stream;
+    stream.start(u, v, x, y, z, M);
+    PartialFold<PICP_S1_DOUBLES, NT2, 8> f1;
+    f1.issue(s1part, s1rows, PICP_S1_DOUBLES);
     if (state[ST_STOP] != 0.0) return;
     {
-        const double tot = fold_partials<PICP_S1_DOUBLES, NT2>(s1part, s1rows, PICP_S1_DOUBLES, lds);
+        const double tot = f1.finish(s1part, s1rows, PICP_S1_DOUBLES, lds);
         if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = tot;
         __syncthreads();
     }
@@ -197,7 +218,7 @@ __global__ __launch_bounds__(NT2) void stage2_kernel(const double* __restrict__ 
     const bool all = (state[ST_MODE] != 0.0);
     Stage2Sums s;
     s.clear();
-    for_each_correspondence<VEC, NT2>(u, v, x, y, z, M, [&](double mu, double mv, double px, double py, double pz) {
+    stream.run([&](double mu, double mv, double px, double py, double pz) {
         stage2_point<PINHOLE>(T, cam, thr, mean, all, mu, mv, px, py, pz, s);
     });
     double vals[S2_USED];
@@ -226,25 +247,27 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
     __shared__ double lds[NT_SOLVE];
     __shared__ double s1[PICP_S1_DOUBLES];
     __shared__ double s2[PICP_S2_DOUBLES];
-    if (state[ST_STOP] != 0.0) return;
+    // The serial step runs on one lane against copies of the state block and the history row in
+    // LDS; both are moved to and from global memory by the whole workgroup.  All global loads of
+    // the prologue -- both sets of partial records and the state block -- are issued before the
+    // first wait, so the kernel pays one memory round trip, not three.
+    __shared__ double st[PICP_STATE_DOUBLES];
+    __shared__ double row[PICP_HIST_STRIDE];
+    PartialFold<PICP_S1_DOUBLES, NT_SOLVE, 4> f1;
+    PartialFold<PICP_S2_DOUBLES, NT_SOLVE, 32> f2;
+    f1.issue(s1part, s1rows, PICP_S1_DOUBLES);
+    f2.issue(s2part, s2rows, PICP_S2_DOUBLES); // stage 2 always leaves valid records (zeros if stage 1 kept nothing)
+    const double mine = (threadIdx.x < PICP_STATE_DOUBLES) ? state[threadIdx.x] : 0.0;
+    if (threadIdx.x < PICP_STATE_DOUBLES) st[threadIdx.x] = mine;
+    __syncthreads();
+    if (st[ST_STOP] != 0.0) return;
     {
-        const double t1 = fold_partials<PICP_S1_DOUBLES, NT_SOLVE>(s1part, s1rows, PICP_S1_DOUBLES, lds);
+        const double t1 = f1.finish(s1part, s1rows, PICP_S1_DOUBLES, lds);
         if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = t1;
-        __syncthreads();
-        // stage 2 wrote nothing meaningful when stage 1 kept nothing; do not read it then
-        const bool have2 = (s1[S1_COUNT] != 0.0);
-        const double t2 =
-            have2 ? fold_partials<PICP_S2_DOUBLES, NT_SOLVE, 32>(s2part, s2rows, PICP_S2_DOUBLES, lds) : 0.0;
+        const double t2 = f2.finish(s2part, s2rows, PICP_S2_DOUBLES, lds);
         if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = t2;
         __syncthreads();
     }
-    // The serial step runs on one lane against copies of the state block and the history row in
-    // LDS; both are moved to and from global memory by the whole workgroup, so the lane never
-    // waits on a global-memory round trip between dependent scalar steps.
-    __shared__ double st[PICP_STATE_DOUBLES];
-    __shared__ double row[PICP_HIST_STRIDE];
-    if (threadIdx.x < PICP_STATE_DOUBLES) st[threadIdx.x] = state[threadIdx.x];
-    __syncthreads();
     __shared__ int advanced;
     const int it = (int)st[ST_IT];
     const bool record = (hist != nullptr && it < hist_rows);
