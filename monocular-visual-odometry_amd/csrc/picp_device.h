@@ -234,78 +234,65 @@ __device__ __forceinline__ double dpp_move(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// Cross-lane exchange primitives for one lane-id bit.  Each returns, for a pair of values (a, b),
+// "my half plus the partner lane's same half": lanes whose bit is 0 get a_self + a_partner, lanes
+// whose bit is 1 get b_self + b_partner, where the partner differs in that bit and agrees in all
+// higher bits.  Bits 5 and 4 are the gfx950 lane swaps, bits 3..1 select + DPP move.
+__device__ __forceinline__ double halve_bit5(double a, double b) {
+    const u32x2_t lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+__device__ __forceinline__ double halve_bit4(double a, double b) {
+    const u32x2_t lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+template <int CTRL>
+__device__ __forceinline__ double halve_dpp(double a, double b, bool up) {
+    const double keep = up ? b : a;
+    const double send = up ? a : b;
+    return keep + dpp_move<CTRL>(send);
+}
+
 // Column sums of a 64 x N matrix held one row per lane (N = 32 or 64): v[j] of lane l is element
-// (l, j); on return lane l (l < N) holds the sum over all 64 lanes of v[l].  Halving steps: at the
-// step for lane-id bit b a lane keeps the half of its values that its own bit selects and receives
-// the partner lane's partial sums of that same half, so the work halves every step (about 250
-// instructions instead of N full butterflies).  Bits 5 and 4 use the gfx950 lane swaps
-// (v_permlane32_swap / v_permlane16_swap), bits 3..0 DPP row_mirror, row_half_mirror and quad
-// permutes, all of which pair a lane with one whose bit b differs and whose higher bits agree.
-// With N = 32 the bit-5 step is a plain pairwise add (both halves keep all 32 sums).
+// (l, j).  Halving steps: at the step for lane-id bit b a lane keeps the half of its values that its
+// own bit selects and receives the partner lane's partial sums of that same half, so the work
+// halves every step -- about 2N exchanges in all instead of 6N for N independent butterflies.
+//   N = 64: six halving steps (bits 5..0); lane l ends with the total of value l.
+//   N = 32: five halving steps (bits 5..1) and one plain pairwise add (bit 0); lanes 2k and 2k+1
+//           both end with the total of value k.
+// Partners: bit 5/4 by v_permlane32_swap / v_permlane16_swap, bit 3 row_mirror (15 - l within a row
+// of 16), bit 2 row_half_mirror (7 - l within 8), bit 1 and bit 0 quad permutes (l ^ 2, l ^ 1).
 // The order of additions is fixed, so the result is reproducible.
 template <int N>
 __device__ __forceinline__ double wave_column_sums(double (&v)[N]) {
     static_assert(N == 32 || N == 64, "32 or 64 values per lane");
     const int lane = threadIdx.x & 63;
-    // bit 5
-    if (N == 64) {
+    constexpr int H5 = N / 2, H4 = N / 4, H3 = N / 8, H2 = N / 16, H1 = N / 32;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const u32x2_t lo = __builtin_amdgcn_permlane32_swap(__double2loint(v[i]), __double2loint(v[(i + 32) % N]), false, false);
-            const u32x2_t hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v[i]), __double2hiint(v[(i + 32) % N]), false, false);
-            v[i] = __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
-        }
-    } else {
+    for (int i = 0; i < H5; ++i) v[i] = halve_bit5(v[i], v[i + H5]);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const u32x2_t lo = __builtin_amdgcn_permlane32_swap(__double2loint(v[i]), __double2loint(v[i]), false, false);
-            const u32x2_t hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v[i]), __double2hiint(v[i]), false, false);
-            v[i] = __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
-        }
-    }
-    // bit 4
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const u32x2_t lo = __builtin_amdgcn_permlane16_swap(__double2loint(v[i]), __double2loint(v[i + 16]), false, false);
-        const u32x2_t hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v[i]), __double2hiint(v[i + 16]), false, false);
-        v[i] = __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
-    }
-    // bit 3: partner = 15 - (lane % 16) within the row
+    for (int i = 0; i < H4; ++i) v[i] = halve_bit4(v[i], v[i + H4]);
     {
         const bool up = (lane & 8) != 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double keep = up ? v[i + 8] : v[i];
-            const double send = up ? v[i] : v[i + 8];
-            v[i] = keep + dpp_move<0x140>(send); // row_mirror
-        }
+        for (int i = 0; i < H3; ++i) v[i] = halve_dpp<0x140>(v[i], v[i + H3], up); // row_mirror
     }
-    // bit 2: partner = 7 - (lane % 8) within the half row
     {
         const bool up = (lane & 4) != 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double keep = up ? v[i + 4] : v[i];
-            const double send = up ? v[i] : v[i + 4];
-            v[i] = keep + dpp_move<0x141>(send); // row_half_mirror
-        }
+        for (int i = 0; i < H2; ++i) v[i] = halve_dpp<0x141>(v[i], v[i + H2], up); // row_half_mirror
     }
-    // bit 1: partner = lane ^ 2
     {
         const bool up = (lane & 2) != 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double keep = up ? v[i + 2] : v[i];
-            const double send = up ? v[i] : v[i + 2];
-            v[i] = keep + dpp_move<0x4E>(send); // quad_perm [2,3,0,1]
-        }
+        for (int i = 0; i < H1; ++i) v[i] = halve_dpp<0x4E>(v[i], v[i + H1], up); // quad_perm [2,3,0,1]
     }
-    // bit 0: partner = lane ^ 1
-    {
-        const bool up = (lane & 1) != 0;
-        const double keep = up ? v[1] : v[0];
-        const double send = up ? v[0] : v[1];
-        v[0] = keep + dpp_move<0xB1>(send); // quad_perm [1,0,3,2]
+    if (N == 64) {
+        v[0] = halve_dpp<0xB1>(v[0], v[1], (lane & 1) != 0); // quad_perm [1,0,3,2]
+    } else {
+        v[0] = v[0] + dpp_move<0xB1>(v[0]);
     }
     return v[0];
 }
@@ -321,13 +308,15 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
     const int wave = threadIdx.x >> 6;
     double out = 0.0;
     if (NV > 8) {
-        // With 32 values the lane -> value map of wave_column_sums is lane % 32 for both halves.
         constexpr int N = (NV <= 32) ? 32 : 64;
         double v[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = (i < NV) ? vals[i] : 0.0;
         const double tot = wave_column_sums<N>(v);
-        if (lane < N) lds[wave * 64 + lane] = tot;
+        if (N == 64)
+            lds[wave * 64 + lane] = tot;
+        else if ((lane & 1) == 0)
+            lds[wave * 64 + (lane >> 1)] = tot; // with 32 values, lanes 2k and 2k+1 hold the total of value k
         __syncthreads();
         if (threadIdx.x < NV) {
 #pragma unroll
