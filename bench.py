@@ -67,9 +67,9 @@ def device_problem(ctx, M, lo, hi, seed=0, chunk=1 << 22):
 
 
 def time_stage2(ctx, pkg, corr, cam, sched, reps=40):
-    """Mean duration of one stage-2 launch, from HIP events recorded on the launch stream around
-    each launch (torch's current stream is the stream the library launches on)."""
-    import torch
+    """Mean and minimum duration of one stage-2 launch, from HIP events bound to each dispatch on
+    the launch stream (picp_profile_stage2: hipExtLaunchKernelGGL start/stop events, i.e. the
+    kernel's own begin/end timestamps, the interval a rocprofv3 kernel trace reports)."""
     L = pkg._lib
     lib, h = ctx.lib, ctx.handle
     M = int(corr[0].numel())
@@ -78,17 +78,12 @@ def time_stage2(ctx, pkg, corr, cam, sched, reps=40):
     ptrs = [ctx.ptr(c) for c in corr]
     L.check(lib.picp_state_init(h, ctx.ptr(state), pose.ctypes.data_as(C.c_void_p), C.byref(sched)), "state_init")
     L.check(lib.picp_stage1(h, *ptrs, M, ctx.ptr(state), C.byref(cam)), "stage1")
-    for _ in range(3):
-        L.check(lib.picp_stage2(h, *ptrs, M, ctx.ptr(state), C.byref(cam), None), "stage2")
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-    for k in range(reps):
-        starts[k].record()
-        L.check(lib.picp_stage2(h, *ptrs, M, ctx.ptr(state), C.byref(cam), None), "stage2")
-        ends[k].record()
-    torch.cuda.synchronize()
-    ms = np.array([s.elapsed_time(e) for s, e in zip(starts, ends)])
-    return float(ms.mean()), float(ms.min())
+    mean_ms, min_ms = C.c_double(), C.c_double()
+    L.check(lib.picp_profile_stage2(h, *ptrs, M, ctx.ptr(state), C.byref(cam), 5, C.byref(mean_ms), C.byref(min_ms)),
+            "warm")
+    L.check(lib.picp_profile_stage2(h, *ptrs, M, ctx.ptr(state), C.byref(cam), reps, C.byref(mean_ms),
+                                    C.byref(min_ms)), "picp_profile_stage2")
+    return float(mean_ms.value), float(min_ms.value)
 
 
 def pmc_traffic(M, world):

@@ -148,6 +148,12 @@ int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x
 int picp_stage2_reduce(picp_ctx* ctx, double* s2);
 int picp_solve(picp_ctx* ctx, double* state, const picp_schedule* sched, const double* s1, const double* s2,
                double* hist, int32_t hist_rows);
+/* Timing aid for benchmarks: launches the stage-2 scan `reps` times, each dispatch bracketed by HIP
+ * events bound to that dispatch (hipExtLaunchKernelGGL), and reports the mean and minimum kernel
+ * duration in milliseconds.  Needs a preceding picp_stage1 on the same ctx.  Synchronises. */
+int picp_profile_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                        const double* z, int64_t M, const double* state, const picp_camera* cam, int32_t reps,
+                        double* mean_ms, double* min_ms);
 /* Reads the history back (synchronises) and applies the best-iteration rule (:249-257). */
 int picp_finish(picp_ctx* ctx, const double* state, const double* hist, int32_t hist_rows,
                 const double* w_T_c0_host, picp_result* result);

@@ -71,6 +71,8 @@ _SIGNATURES = {
     "picp_stage1_reduce": (C.c_int, [_P, _P]),
     "picp_stage2": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), _P]),
     "picp_stage2_reduce": (C.c_int, [_P, _P]),
+    "picp_profile_stage2": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_int32,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "picp_solve": (C.c_int, [_P, _P, C.POINTER(ScheduleStruct), _P, _P, _P, C.c_int32]),
     "picp_finish": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.POINTER(ResultStruct)]),
     "picp_linearize": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_double,

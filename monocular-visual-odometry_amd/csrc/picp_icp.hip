@@ -9,6 +9,8 @@
 // Both are HBM-bound streams of five float64 arrays; every workgroup leaves one record of
 // partial sums, and the next kernel in the chain folds those records in its prologue (a kernel
 // boundary is cheaper here than an in-kernel device-wide barrier).
+#include <hip/hip_ext.h>
+
 #include "picp_common.h"
 #include "picp_device.h"
 
@@ -478,6 +480,46 @@ int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p, s1rows,
                        ctx->part2);
     PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+int picp_profile_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                        const double* z, int64_t M, const double* state, const picp_camera* cam, int32_t reps,
+                        double* mean_ms, double* min_ms) {
+    PICP_REQUIRE(ctx && state && cam && mean_ms && min_ms && reps > 0, "picp_profile_stage2: bad argument");
+    if (int rc = check_corr(u, v, x, y, z, M)) return rc;
+    DeviceGuard g(ctx->device);
+    const CameraK c = to_device_camera(cam);
+    const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
+    const int grid = grid_for(vec ? (M + 1) / 2 : M, NT2, ctx->max_blocks2);
+    ctx->rows2 = grid;
+    auto kern = vec ? (is_pinhole(cam->K) ? stage2_kernel<2, true> : stage2_kernel<2, false>)
+                    : (is_pinhole(cam->K) ? stage2_kernel<1, true> : stage2_kernel<1, false>);
+    hipEvent_t e0, e1;
+    PICP_HIP_CHECK(hipEventCreate(&e0));
+    PICP_HIP_CHECK(hipEventCreate(&e1));
+    double sum = 0.0, best = 1e30;
+    for (int r = 0; r < reps; ++r) {
+        // start/stop events bound to this one dispatch: they carry the kernel's own begin and end
+        // timestamps, the same interval a kernel trace reports
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NT2), 0, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, c,
+                              (const double*)ctx->part1, ctx->rows1, ctx->part2);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return hip_fail(e, "picp_profile_stage2");
+        }
+        sum += ms;
+        if (ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *mean_ms = sum / reps;
+    *min_ms = best;
     return PICP_OK;
 }
 
