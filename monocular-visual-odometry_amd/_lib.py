@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpicp_hip.so")
+# PICP_LIB selects another build of the same library (A/B timing of kernel variants on one box).
+LIB_PATH = os.environ.get("PICP_LIB") or os.path.join(_HERE, "csrc", "libpicp_hip.so")
 
 HIST_STRIDE = 80
 STATE_DOUBLES = 96

@@ -585,8 +585,25 @@ struct StepRecord {
 // Returns false when the iteration could not be completed because the stage-2 record holds the
 // mean-filtered set F and F has fewer than min_inliers members: the state's mode flag is then set
 // and nothing else changes; the caller runs the stages again (stage 2 then sums the stage-1 set).
+// Fills the H, b and padding entries of a history row from the stage records.  These do not depend
+// on the serial step, so the lanes that would otherwise idle write them (tid = 0..63 of any wave).
+__device__ __forceinline__ void fill_history_linear(double* hist_row, const double* s1, const double* s2, int tid) {
+    const bool have = (s1[S1_N_INSIDE] != 0.0) && (s1[S1_COUNT] != 0.0);
+    if (tid < 36) {
+        const int i = tid / 6, j = tid % 6;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int tri = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo); // index of (lo, hi) in the row-major upper triangle
+        hist_row[PICP_H_H + tid] = have ? s2[S2_H + tri] : 0.0;
+    } else if (tid < 42) {
+        hist_row[PICP_H_B + (tid - 36)] = have ? s2[S2_B + (tid - 36)] : 0.0;
+    } else if (tid < 42 + (PICP_HIST_STRIDE - (PICP_H_H + 36))) {
+        hist_row[PICP_H_H + 36 + (tid - 42)] = 0.0;
+    }
+}
+
+// linear_by_others: the caller fills H, b and the padding of the history row with fill_history_linear.
 __device__ inline bool solve_and_schedule(double* st, const double* s1, const double* s2, const picp_schedule& sc,
-                                          double* hist_row) {
+                                          double* hist_row, bool linear_by_others = false) {
     const double n_inside = s1[S1_N_INSIDE];
     const double n1 = s1[S1_COUNT];
     const bool redo_mode = (st[ST_MODE] != 0.0);
@@ -737,13 +754,14 @@ __device__ inline bool solve_and_schedule(double* st, const double* s1, const do
         hist_row[PICP_H_USED_STAGE2] = r.used_stage2;
         hist_row[PICP_H_MEAN_STAGE1] = r.mean_stage1;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            hist_row[PICP_H_DX + i] = r.dx[i];
-            hist_row[PICP_H_B + i] = r.b[i];
-        }
+        for (int i = 0; i < 6; ++i) hist_row[PICP_H_DX + i] = r.dx[i];
+        if (!linear_by_others) {
 #pragma unroll
-        for (int i = 0; i < 36; ++i) hist_row[PICP_H_H + i] = r.H[i];
-        for (int i = PICP_H_H + 36; i < PICP_HIST_STRIDE; ++i) hist_row[i] = 0.0;
+            for (int i = 0; i < 6; ++i) hist_row[PICP_H_B + i] = r.b[i];
+#pragma unroll
+            for (int i = 0; i < 36; ++i) hist_row[PICP_H_H + i] = r.H[i];
+            for (int i = PICP_H_H + 36; i < PICP_HIST_STRIDE; ++i) hist_row[i] = 0.0;
+        }
     }
     return true;
 }

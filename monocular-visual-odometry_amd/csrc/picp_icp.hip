@@ -273,7 +273,8 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
     __shared__ int advanced;
     const int it = (int)st[ST_IT];
     const bool record = (hist != nullptr && it < hist_rows);
-    if (threadIdx.x == 0) advanced = solve_and_schedule(st, s1, s2, sc, record ? row : nullptr) ? 1 : 0;
+    if (threadIdx.x == 0) advanced = solve_and_schedule(st, s1, s2, sc, record ? row : nullptr, true) ? 1 : 0;
+    if (record && threadIdx.x >= 64 && threadIdx.x < 128) fill_history_linear(row, s1, s2, threadIdx.x - 64);
     __syncthreads();
     if (threadIdx.x < PICP_STATE_DOUBLES) state[threadIdx.x] = st[threadIdx.x];
     if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
