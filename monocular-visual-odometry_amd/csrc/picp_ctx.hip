@@ -1,4 +1,6 @@
 // Context life cycle and error reporting of libpicp_hip.so.
+#include <stdlib.h>
+
 #include "picp_common.h"
 
 namespace picp {
@@ -49,12 +51,16 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(stream);
     ctx->num_cus = prop.multiProcessorCount;
-    // Stage 1: two 256-thread workgroups per CU (measured: four per CU is slower at 2^20
-    // correspondences, the extra waves only lengthen the launch ramp and the partial fold).
-    // Stage 2 keeps 58 accumulator registers per lane and fits 128 registers in all, i.e. four waves
-    // per SIMD: two 512-thread workgroups per CU.
+    // Workgroups per CU of the two scans, from sweeps on MI355X (2^20 .. 2^25 correspondences):
+    // both scans keep two register sets of loads in flight per lane, so more resident waves buy no
+    // bandwidth and only add partial records, launch ramp and reduction work.  Stage 1: two
+    // 256-thread workgroups per CU (one for very large inputs, see grid_for callers); stage 2: one
+    // 512-thread workgroup per CU.
     ctx->max_blocks1 = 2 * ctx->num_cus;
-    ctx->max_blocks2 = 2 * ctx->num_cus;
+    ctx->max_blocks2 = ctx->num_cus;
+    // Tuning overrides (workgroups per CU), for experiments only.
+    if (const char* e1 = getenv("PICP_STAGE1_WG_PER_CU")) { int k = atoi(e1); if (k >= 1 && k <= 8) ctx->max_blocks1 = k * ctx->num_cus; }
+    if (const char* e2 = getenv("PICP_STAGE2_WG_PER_CU")) { int k = atoi(e2); if (k >= 1 && k <= 4) ctx->max_blocks2 = k * ctx->num_cus; }
     hipError_t e = hipMalloc(&ctx->part1, sizeof(double) * PICP_S1_DOUBLES * ctx->max_blocks1);
     if (e == hipSuccess) e = hipMalloc(&ctx->part2, sizeof(double) * PICP_S2_DOUBLES * ctx->max_blocks2);
     if (e == hipSuccess) e = hipMalloc(&ctx->scratch, sizeof(double) * SCR_DOUBLES);

@@ -17,8 +17,8 @@
 namespace picp {
 
 constexpr int NT = 256;  // threads per workgroup of the stage-1 scan, the batched kernel and the small kernels
-constexpr int NT2 = 512; // stage-2 scan: workgroups of eight waves, two per CU (128 registers per lane = four waves
-                         // per SIMD), so a launch leaves at most two partial records per CU to fold
+constexpr int NT2 = 512; // stage-2 scan: one workgroup of eight waves per CU, so a launch leaves at most one partial
+                         // record per CU to fold
 
 struct Pose16 {
     double m[16];
@@ -447,7 +447,9 @@ int picp_stage1(picp_ctx* ctx, const double* u, const double* v, const double* x
     DeviceGuard g(ctx->device);
     const CameraK c = to_device_camera(cam);
     const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
-    const int grid = grid_for(vec ? (M + 1) / 2 : M, NT, ctx->max_blocks1);
+    // above ~4M correspondences one workgroup per CU streams as fast and leaves half the records
+    const int cap1 = (M > (int64_t(1) << 22) && ctx->max_blocks1 == 2 * ctx->num_cus) ? ctx->num_cus : ctx->max_blocks1;
+    const int grid = grid_for(vec ? (M + 1) / 2 : M, NT, cap1);
     ctx->rows1 = grid;
     auto kern = vec ? (is_pinhole(cam->K) ? stage1_kernel<2, true> : stage1_kernel<2, false>)
                     : (is_pinhole(cam->K) ? stage1_kernel<1, true> : stage1_kernel<1, false>);
