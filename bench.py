@@ -9,8 +9,16 @@ correspondence set that is already resident in HBM.  N = 1 runs the single-GPU c
 all-reduces per iteration.  Rank 0 prints one JSON line.
 
 metric = correspondence-iterations per second, whole job.
-roofline = the stage-2 scan (linearise + H/b reduction): algorithmic bytes (40 B per
-correspondence per launch) over its mean launch duration, against the 8 TB/s HBM3E peak.
+roofline = the dominant kernel against the 8 TB/s HBM3E peak, algorithmic bytes over its mean
+launch duration (HIP events bound to the dispatch):
+  * N = 1, 2^20 correspondences: the single-launch loop kernel (correspondences held in registers
+    for all 20 iterations).  Algorithmic bytes follow the reference's data flow, two passes of 40 B
+    per correspondence per iteration = 80 B x M x 20 per launch, although the kernel reads the
+    arrays from HBM only once ("hbm_bytes_read_once").
+  * sharded runs (inputs too large for the register files): the stage-2 scan (linearise + H/b
+    reduction), 40 B per correspondence per launch.
+  "streaming_scan" reports that stage-2 figure for the N = 1 workload as well, and
+  "streaming_scan_hbm_resident" for an input larger than the 256 MB Infinity Cache.
 cpu_baseline = the numpy restatement (oracle/) on the host, on a bounded sample.
 """
 from __future__ import annotations
@@ -40,7 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--corr", type=int, default=0, help="total correspondences (default 2^20 at 1 GPU, 2^26 sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iterations", type=int, default=10)
+    ap.add_argument("--no-large-scan", action="store_true", help="skip the 2^24-correspondence stage-2 timing")
+    ap.add_argument("--cpu-iterations", type=int, default=60)
     return ap.parse_args()
 
 
@@ -86,22 +95,35 @@ def time_stage2(ctx, pkg, corr, cam, sched, reps=40):
     return float(mean_ms.value), float(min_ms.value)
 
 
-def pmc_traffic(M, world):
-    """HBM bytes per stage-2 launch from the committed rocprofv3 counter passes (FETCH_SIZE and
+def time_resident(ctx, pkg, corr, cam, sched, reps=20):
+    """Mean and minimum duration of the single-launch loop kernel (picp_profile_run: events bound
+    to the dispatch, the interval a rocprofv3 kernel trace reports)."""
+    L = pkg._lib
+    M = int(corr[0].numel())
+    state = ctx.empty(L.STATE_DOUBLES)
+    pose = np.ascontiguousarray(np.eye(4).reshape(16))
+    args = [ctx.handle, *[ctx.ptr(c) for c in corr], M, pose.ctypes.data_as(C.c_void_p), C.byref(cam), C.byref(sched),
+            ctx.ptr(state)]
+    mean_ms, min_ms = C.c_double(), C.c_double()
+    L.check(ctx.lib.picp_profile_run(*args, 3, C.byref(mean_ms), C.byref(min_ms)), "warm")
+    L.check(ctx.lib.picp_profile_run(*args, reps, C.byref(mean_ms), C.byref(min_ms)), "picp_profile_run")
+    return float(mean_ms.value), float(min_ms.value)
+
+
+def pmc_traffic(M, world, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE and
     WRITE_SIZE, separate runs of this same command; profiles/summarize.py applies the gfx950
     corrections).  Counters cannot be read from inside the process, so the figure is only reported
     for the workload it was collected on."""
     import glob
     if world != 1 or M != (1 << 20):
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_2p20.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as fh:
-        k = json.load(fh)["kernels"]
-    for name, v in k.items():
-        if "stage2_kernel" in name:
-            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_2p20*.json")), reverse=True):
+        with open(path) as fh:
+            k = json.load(fh)["kernels"]
+        for name, v in k.items():
+            if kernel in name:
+                return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -186,11 +208,41 @@ def main():
         dt = float(t.item())
     assert res.num_iterations == ITERATIONS, res.num_iterations
 
+    n_local = hi - lo
     s2_mean_ms, s2_min_ms = time_stage2(ctx, pkg, corr, cam, sched)
+    resident = world == 1 and 0 < M <= ctx.resident_capacity()
+    if resident:
+        run_mean_ms, run_min_ms = time_resident(ctx, pkg, corr, cam, sched)
+    big = None
+    if rank == 0 and world == 1 and not args.no_large_scan:
+        # the same scan on an input that cannot live in the 256 MB Infinity Cache
+        Mb = 1 << 24
+        corr_b = device_problem(ctx, Mb, 0, Mb, seed=1)
+        b_mean, b_min = time_stage2(ctx, pkg, corr_b, cam, sched, reps=20)
+        big = {"correspondences": Mb, "bytes_per_launch": BYTES_PER_CORR_PER_SCAN * Mb, "mean_launch_ms": b_mean,
+               "min_launch_ms": b_min, "achieved": BYTES_PER_CORR_PER_SCAN * Mb / (b_mean * 1e-3) / 1e9,
+               "frac": BYTES_PER_CORR_PER_SCAN * Mb / (b_mean * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del corr_b
     if rank == 0:
-        n_local = hi - lo
-        achieved = BYTES_PER_CORR_PER_SCAN * n_local / (s2_mean_ms * 1e-3) / 1e9
-        traffic, traffic_source = pmc_traffic(M, world)
+        scan = {"kernel": "stage2_kernel (linearise + H/b reduction)",
+                "bytes_per_launch": BYTES_PER_CORR_PER_SCAN * n_local,
+                "mean_launch_ms": s2_mean_ms, "min_launch_ms": s2_min_ms,
+                "achieved": BYTES_PER_CORR_PER_SCAN * n_local / (s2_mean_ms * 1e-3) / 1e9}
+        scan["frac"] = scan["achieved"] / HBM_PEAK_GBS
+        if resident:
+            kernel = "icp_resident_kernel"
+            bytes_per_launch = 2 * BYTES_PER_CORR_PER_SCAN * n_local * ITERATIONS
+            achieved = bytes_per_launch / (run_mean_ms * 1e-3) / 1e9
+            roof = {"kernel": "icp_resident_kernel (whole loop in one launch, correspondences in registers)",
+                    "bytes_per_launch": bytes_per_launch, "mean_launch_ms": run_mean_ms, "min_launch_ms": run_min_ms,
+                    "hbm_bytes_read_once": BYTES_PER_CORR_PER_SCAN * n_local,
+                    "note": "algorithmic bytes = 80 B per correspondence-iteration (two 40 B passes, the "
+                            "reference's data flow); the kernel itself reads each array once per launch"}
+        else:
+            kernel = "stage2_kernel"
+            achieved = scan["achieved"]
+            roof = {k: scan[k] for k in ("kernel", "bytes_per_launch", "mean_launch_ms", "min_launch_ms")}
+        traffic, traffic_source = pmc_traffic(M, world, kernel)
         out = {
             "metric": "ICP correspondence-iterations/sec",
             "value": M * ITERATIONS * args.steps / dt,
@@ -206,14 +258,14 @@ def main():
                                     f"synthetic single-pose projective ICP, {M} correspondences sharded over "
                                     f"{world} GPU(s), 20 LM iterations, 2 all-reduces per iteration"),
                        "correspondences": M, "lm_iterations": ITERATIONS,
+                       "device_path": "single launch, register-resident" if resident else "streaming stage launches",
                        "final_pose_error": float(np.max(np.abs(np.array(list(res.T)).reshape(4, 4) - true_pose())))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "stage2_kernel (linearise + H/b reduction)",
-                         "bytes_per_launch": BYTES_PER_CORR_PER_SCAN * n_local,
-                         "mean_launch_ms": s2_mean_ms, "min_launch_ms": s2_min_ms,
+                         **roof,
                          "loop_bytes_per_corr_iteration": 2 * BYTES_PER_CORR_PER_SCAN,
-                         "loop_achieved_GBs": 2 * BYTES_PER_CORR_PER_SCAN * n_local * ITERATIONS * args.steps / dt / 1e9},
+                         "loop_achieved_GBs": 2 * BYTES_PER_CORR_PER_SCAN * n_local * ITERATIONS * args.steps / dt / 1e9,
+                         "streaming_scan": scan, "streaming_scan_hbm_resident": big},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, args.cpu_iterations)

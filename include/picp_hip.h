@@ -116,6 +116,21 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
              int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched,
              double* state, double* hist, int32_t hist_rows, picp_result* result);
 
+/* picp_run has two device paths with the same results (sums differ only in the order of additions):
+ * up to picp_resident_capacity(ctx) correspondences the whole loop is ONE launch that reads the five
+ * arrays once and keeps them in registers, exchanging the two per-iteration sums of :301 and :313-317
+ * between workgroups inside the kernel; larger inputs stream the arrays twice per iteration through
+ * separate launches.  picp_set_resident_limit lowers the switch point (0 = always stream); the
+ * capacity is a property of the device (CUs x threads x registers). */
+int picp_set_resident_limit(picp_ctx* ctx, int64_t max_correspondences);
+int64_t picp_resident_capacity(picp_ctx* ctx);
+/* Timing aid for benchmarks: runs the single-launch loop `reps` times from w_T_c0_host, each launch
+ * bracketed by HIP events bound to that dispatch, and reports the mean and minimum kernel duration
+ * in milliseconds.  M must not exceed picp_resident_capacity.  Synchronises. */
+int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                     const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
+                     const picp_schedule* sched, double* state, int32_t reps, double* mean_ms, double* min_ms);
+
 /* Same loop for B independent problems in one launch, one workgroup per problem, the whole loop
  * inside the kernel.  Problem p owns correspondences [offsets[p], offsets[p+1]).
  * offsets: device int64[B+1]; poses0: device [B][16]; results: device picp_result[B];

@@ -65,6 +65,11 @@ _SIGNATURES = {
     "picp_synchronize": (C.c_int, [_P]),
     "picp_run": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
                            C.POINTER(ScheduleStruct), _P, _P, C.c_int32, C.POINTER(ResultStruct)]),
+    "picp_set_resident_limit": (C.c_int, [_P, C.c_int64]),
+    "picp_resident_capacity": (C.c_int64, [_P]),
+    "picp_profile_run": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
+                                   C.POINTER(ScheduleStruct), _P, C.c_int32, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
     "picp_run_batched": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(CameraStruct),
                                    C.POINTER(ScheduleStruct), _P, _P, C.c_int32]),
     "picp_state_init": (C.c_int, [_P, _P, _P, C.POINTER(ScheduleStruct)]),
@@ -218,6 +223,15 @@ class Context:
         return [d[k][:M] for k in range(5)]
 
     # ---- loop ----------------------------------------------------------------------------------
+    def set_resident_limit(self, max_correspondences=None):
+        """Largest input for which picp_run uses its single-launch, register-resident loop
+        (None: whatever fits the device; 0: always the streaming kernels)."""
+        n = (1 << 62) if max_correspondences is None else int(max_correspondences)
+        check(self.lib.picp_set_resident_limit(self.handle, n), "picp_set_resident_limit")
+
+    def resident_capacity(self):
+        return int(self.lib.picp_resident_capacity(self.handle))
+
     def run(self, corr, w_T_c0, cam: CameraStruct, sched: ScheduleStruct, want_history=True):
         """picp_run on device arrays corr = [u, v, x, y, z].  Returns (ResultStruct, history ndarray)."""
         M = int(corr[0].numel())

@@ -792,4 +792,62 @@ __device__ inline void init_state(double* st, const double* pose, double thr, do
     st[ST_BEST_IT] = 0.0;
 }
 
+// ---- per-correspondence work of the two stages (shared by the streaming scans, the batched kernel
+// and the register-resident loop kernel) ----------------------------------------------------------
+struct Stage1Sums {
+    double sum_chi;
+    unsigned n1, n_inside;
+};
+
+template <bool PINHOLE>
+__device__ __forceinline__ void stage1_point(const double* __restrict__ T, const CameraK& cam, double thr, double mu,
+                                             double mv, double x, double y, double z, Stage1Sums& s) {
+    const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
+    const double e0 = mu - p.u, e1 = mv - p.v;         // src/ProjectiveICP.py:333
+    const double chi = e0 * e0 + e1 * e1;              // :293
+    const bool keep = p.inside && (chi <= thr);        // :290, :294
+    s.n_inside += p.inside ? 1u : 0u;
+    s.n1 += keep ? 1u : 0u;
+    s.sum_chi += keep ? chi : 0.0;
+}
+
+struct Stage2Sums {
+    SetSums S;
+    double chi;
+    unsigned n;
+    __device__ __forceinline__ void clear() {
+        S.clear();
+        chi = 0.0;
+        n = 0u;
+    }
+};
+
+// `all` = the state's mode flag: false sums the mean-filtered set (chi < mean, strict,
+// src/ProjectiveICP.py:302), true the whole stage-1 set.
+template <bool PINHOLE>
+__device__ __forceinline__ void stage2_point(const double* __restrict__ T, const CameraK& cam, double thr, double mean,
+                                             bool all, double mu, double mv, double x, double y, double z,
+                                             Stage2Sums& s) {
+    const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
+    const double e0 = mu - p.u, e1 = mv - p.v;
+    const double chi = e0 * e0 + e1 * e1;
+    const bool keep = p.inside && (chi <= thr) && (all || chi < mean);
+    if (keep) {
+        double J0[6], J1[6];
+        jacobian_rows<PINHOLE>(p, cam, J0, J1);
+        s.S.add<PINHOLE>(J0, J1, e0, e1);
+        s.chi += chi;
+        s.n += 1u;
+    }
+}
+
+__device__ __forceinline__ void pack_sets(const Stage2Sums& s, double (&vals)[S2_USED]) {
+#pragma unroll
+    for (int i = 0; i < 21; ++i) vals[S2_H + i] = s.S.H[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vals[S2_B + i] = s.S.b[i];
+    vals[S2_CHI] = s.chi;
+    vals[S2_N] = (double)s.n;
+}
+
 } // namespace picp

@@ -29,23 +29,6 @@ __global__ void state_init_kernel(double* st, Pose16 pose, double thr, double la
 }
 
 // ---- stage 1 --------------------------------------------------------------------------------
-struct Stage1Sums {
-    double sum_chi;
-    unsigned n1, n_inside;
-};
-
-template <bool PINHOLE>
-__device__ __forceinline__ void stage1_point(const double* __restrict__ T, const CameraK& cam, double thr, double mu,
-                                             double mv, double x, double y, double z, Stage1Sums& s) {
-    const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
-    const double e0 = mu - p.u, e1 = mv - p.v;         // src/ProjectiveICP.py:333
-    const double chi = e0 * e0 + e1 * e1;              // :293
-    const bool keep = p.inside && (chi <= thr);        // :290, :294
-    s.n_inside += p.inside ? 1u : 0u;
-    s.n1 += keep ? 1u : 0u;
-    s.sum_chi += keep ? chi : 0.0;
-}
-
 // Five 16-byte loads = two correspondences per lane.
 struct Corr2 {
     double2 u, v, x, y, z;
@@ -147,45 +130,6 @@ __global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u
 }
 
 // ---- stage 2 --------------------------------------------------------------------------------
-struct Stage2Sums {
-    SetSums S;
-    double chi;
-    unsigned n;
-    __device__ __forceinline__ void clear() {
-        S.clear();
-        chi = 0.0;
-        n = 0u;
-    }
-};
-
-// `all` = the state's mode flag: false sums the mean-filtered set (chi < mean, strict,
-// src/ProjectiveICP.py:302), true the whole stage-1 set.
-template <bool PINHOLE>
-__device__ __forceinline__ void stage2_point(const double* __restrict__ T, const CameraK& cam, double thr, double mean,
-                                             bool all, double mu, double mv, double x, double y, double z,
-                                             Stage2Sums& s) {
-    const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
-    const double e0 = mu - p.u, e1 = mv - p.v;
-    const double chi = e0 * e0 + e1 * e1;
-    const bool keep = p.inside && (chi <= thr) && (all || chi < mean);
-    if (keep) {
-        double J0[6], J1[6];
-        jacobian_rows<PINHOLE>(p, cam, J0, J1);
-        s.S.add<PINHOLE>(J0, J1, e0, e1);
-        s.chi += chi;
-        s.n += 1u;
-    }
-}
-
-__device__ __forceinline__ void pack_sets(const Stage2Sums& s, double (&vals)[S2_USED]) {
-#pragma unroll
-    for (int i = 0; i < 21; ++i) vals[S2_H + i] = s.S.H[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) vals[S2_B + i] = s.S.b[i];
-    vals[S2_CHI] = s.chi;
-    vals[S2_N] = (double)s.n;
-}
-
 template <int VEC, bool PINHOLE>
 __global__ __launch_bounds__(NT2) void stage2_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                     const double* __restrict__ x, const double* __restrict__ y,
@@ -526,6 +470,41 @@ int picp_profile_stage2(picp_ctx* ctx, const double* u, const double* v, const d
     return PICP_OK;
 }
 
+int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
+                     int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched,
+                     double* state, int32_t reps, double* mean_ms, double* min_ms) {
+    PICP_REQUIRE(ctx && cam && sched && state && mean_ms && min_ms && reps > 0, "picp_profile_run: bad argument");
+    if (int rc = check_corr(u, v, x, y, z, M)) return rc;
+    PICP_REQUIRE(M > 0 && M <= resident_capacity(ctx), "picp_profile_run: %lld correspondences do not fit the "
+                 "single-launch loop (capacity %lld)", (long long)M, (long long)resident_capacity(ctx));
+    DeviceGuard g(ctx->device);
+    hipEvent_t e0, e1;
+    PICP_HIP_CHECK(hipEventCreate(&e0));
+    PICP_HIP_CHECK(hipEventCreate(&e1));
+    double sum = 0.0, best = 1e30;
+    int rc = PICP_OK;
+    for (int r = 0; r < reps && rc == PICP_OK; ++r) {
+        rc = picp_state_init(ctx, state, w_T_c0_host, sched);
+        if (rc == PICP_OK) rc = enqueue_resident(ctx, u, v, x, y, z, M, state, cam, sched, nullptr, 0, e0, e1);
+        if (rc != PICP_OK) break;
+        hipError_t e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) {
+            rc = hip_fail(e, "picp_profile_run");
+            break;
+        }
+        sum += ms;
+        if (ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != PICP_OK) return rc;
+    *mean_ms = sum / reps;
+    *min_ms = best;
+    return PICP_OK;
+}
+
 int picp_stage2_reduce(picp_ctx* ctx, double* s2) {
     PICP_REQUIRE(ctx && s2, "picp_stage2_reduce: null argument");
     DeviceGuard g(ctx->device);
@@ -580,6 +559,18 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
                  "picp_run: history has %d rows, num_iterations is %d", hist_rows, sched->num_iterations);
     if (int rc = picp_state_init(ctx, state, w_T_c0_host, sched)) return rc;
     DeviceGuard g(ctx->device);
+    // Inputs that fit the register files run the whole loop in one launch (picp_resident.hip).
+    if (M > 0 && M <= resident_capacity(ctx) && sched->num_iterations > 0) {
+        if (int rc = enqueue_resident(ctx, u, v, x, y, z, M, state, cam, sched, hist, (int)hist_rows, nullptr, nullptr))
+            return rc;
+        unsigned* failed = reinterpret_cast<unsigned*>(ctx->pinned + PICP_STATE_DOUBLES);
+        PICP_HIP_CHECK(hipMemcpyAsync(failed, ctx->rfailed, sizeof(*failed), hipMemcpyDeviceToHost, ctx->stream));
+        if (int rc = picp_finish(ctx, state, hist, hist_rows, w_T_c0_host, result)) return rc; // synchronises
+        if (*failed == 0u) return PICP_OK;
+        // the launch was abandoned at a grid-wide wait (device shared with other work): start over
+        ctx->resident_aborts += 1;
+        if (int rc = picp_state_init(ctx, state, w_T_c0_host, sched)) return rc;
+    }
     // Rounds of {stage 1, stage 2, solve} are enqueued in chunks; between chunks the stop flag is
     // read back, so a loop that converged after a few iterations does not pay for launches that
     // would do nothing (every kernel returns at once when the flag is set, so overshooting is

@@ -1,0 +1,272 @@
+// The whole pose loop in ONE launch with the correspondences held in registers.
+//
+// When M correspondences fit the register files of the chip (one 512-thread workgroup per CU, up to
+// R_MAX correspondences per thread), the five input arrays are read from HBM once; every
+// iteration then works on registers.  The two device-wide sums an iteration needs
+// (src/ProjectiveICP.py:301 needs the mean of chi over all stage-1 survivors before the inlier set
+// of :302-310 can be chosen, and :313-317 sum H and b over that set) are exchanged between the
+// workgroups through small records in global memory:
+//
+//   stage 1 on registers -> workgroup sum -> publish record -> every workgroup collects and folds all records
+//   stage 2 on registers -> workgroup sum -> publish record -> every workgroup collects and folds all records
+//   every workgroup runs the identical 6x6 solve + schedules on its own copy of the loop state
+//
+// All workgroups fold the same records in the same order, so their copies of the state stay
+// bit-identical and control flow (stop test, redo mode) is uniform over the grid without a
+// broadcast.  Larger inputs use the streaming kernels of picp_icp.hip.
+//
+// Exchange without read-modify-write atomics and without cache write-backs (a shared arrival
+// counter serialises 256 arrivals and 256 pollers on one address, and a release fence makes each
+// workgroup write back its whole L2: both cost tens of microseconds per exchange on 256 CUs).
+// Records are written and read with device-scope atomic stores and loads, which go to memory.  A
+// record entry that has not been published yet holds a sentinel -- a NaN bit pattern no sum can
+// produce -- and a reader re-reads an entry until it is not the sentinel, so "has everyone
+// arrived" and "fetch the data" are the same loads.  Three slots rotate: exchange k publishes into
+// slot k%3; when a workgroup has collected all records of exchange k, every workgroup has
+// published there and so has finished reading slot (k-1)%3, and the workgroup resets its record in
+// that slot to the sentinel.  The slot is used again in exchange k+2; a reader gets there only
+// after it has seen this workgroup's exchange-(k+1) record, which is stored after the reset has been
+// acknowledged.
+//
+// Every wait is a bounded spin: the grid is never larger than the number of CUs and a workgroup
+// needs less than one CU, so on an otherwise idle device all workgroups are resident and a wait
+// ends within microseconds.  If the bound is ever hit (the device is shared and part of the grid
+// was not scheduled), the workgroup sets a failure flag and leaves; the others run into their own
+// bounds, the launch ends, and the host repeats the loop with the streaming kernels.  Every wave
+// therefore reaches an exit whatever the scheduling.
+#include <hip/hip_ext.h>
+
+#include "picp_common.h"
+#include "picp_device.h"
+
+namespace picp {
+
+constexpr int NTR = 512;                 // eight waves: two per SIMD
+constexpr int RW = PICP_S2_DOUBLES;      // doubles per exchange record (both stages use one slot layout)
+constexpr int R_MAX = 8;                 // correspondences per thread
+constexpr int SLOTS = 3;
+constexpr int MAX_GRID = 256;            // rows one fold covers with all of a thread's loads in flight
+constexpr unsigned long long SENTINEL_BITS = 0xFFF8C0DEC0DE5EEDull; // a NaN payload arithmetic never produces
+
+struct GridExchange {
+    double* slots;       // [SLOTS][gridDim.x][RW]
+    unsigned* failed;    // set to 1 by a workgroup that gave up waiting
+    unsigned spin_limit; // re-reads before a waiting thread gives up
+};
+
+__device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == SENTINEL_BITS; }
+
+// First launch step: every record of every slot holds the sentinel.
+__global__ void resident_prepare_kernel(double* slots, int n, unsigned* failed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[i] = __longlong_as_double((long long)SENTINEL_BITS);
+    if (i == 0) *failed = 0u;
+}
+
+// Grid-wide sum of NV values.  `mine`: this workgroup's total of value tid (threads tid < NV).
+// On success every thread with tid < NV of EVERY workgroup holds the same grid total in `out`.
+// Returns false (uniformly over the workgroup) when a wait ran into its bound.
+template <int NV, int B>
+__device__ __forceinline__ bool grid_total(double mine, double& out, const GridExchange& gx, unsigned& epoch,
+                                           double* lds, int* lds_flag) {
+    const int G = gridDim.x;
+    if (G == 1) {
+        out = mine;
+        return true;
+    }
+    using Fold = PartialFold<NV, NTR, B>;
+    constexpr int CW = Fold::CW, GR = Fold::G;
+    static_assert(CW <= RW && RW <= 64, "the record is written by the first wave");
+    static_assert(B * GR >= MAX_GRID, "one load per row in flight");
+    double* cur = gx.slots + (size_t)(epoch % SLOTS) * G * RW;
+    double* old = gx.slots + (size_t)((epoch + SLOTS - 1u) % SLOTS) * G * RW; // the previous exchange's slot
+    ++epoch;
+    if (threadIdx.x < CW) {
+        // The reset this wave stored at the end of the previous exchange has been acknowledged
+        // (the stores are write-through at device scope), so it is visible before this record is.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cur + (size_t)blockIdx.x * RW + threadIdx.x, (threadIdx.x < NV) ? mine : 0.0,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // collect: thread (grp, col) owns rows grp, grp + GR, ... of column col
+    const int col = threadIdx.x % CW, grp = threadIdx.x / CW;
+    Fold f;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        const int r = grp + k * GR;
+        f.v[k] = (col < NV && r < G)
+                     ? __hip_atomic_load(cur + (size_t)r * RW + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     : 0.0;
+    }
+    unsigned spins = 0;
+    for (;;) {
+        bool missing = false;
+#pragma unroll
+        for (int k = 0; k < B; ++k) missing |= is_sentinel(f.v[k]);
+        if (!missing) break;
+        if (++spins > gx.spin_limit) {
+            *lds_flag = 1;
+            __hip_atomic_store(gx.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            if (is_sentinel(f.v[k]))
+                f.v[k] = __hip_atomic_load(cur + (size_t)(grp + k * GR) * RW + col, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    out = f.finish(cur, 0, RW, lds); // rows = 0: everything is already in f.v; synchronises the workgroup
+    // Every workgroup has published into `cur`, hence has finished reading `old`: reset this
+    // workgroup's record there; that slot is next used two exchanges from now.
+    if (threadIdx.x < RW)
+        __hip_atomic_store(old + (size_t)blockIdx.x * RW + threadIdx.x, __longlong_as_double((long long)SENTINEL_BITS),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *lds_flag == 0;
+}
+
+template <int R, bool PINHOLE>
+__global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restrict__ u, const double* __restrict__ v,
+                                                          const double* __restrict__ x, const double* __restrict__ y,
+                                                          const double* __restrict__ z, int64_t M,
+                                                          double* __restrict__ state, CameraK cam, picp_schedule sc,
+                                                          GridExchange gx, double* __restrict__ hist, int hist_rows) {
+    __shared__ double st[PICP_STATE_DOUBLES];
+    __shared__ double lds[NTR];
+    __shared__ double s1[PICP_S1_DOUBLES];
+    __shared__ double s2[PICP_S2_DOUBLES];
+    __shared__ double row[PICP_HIST_STRIDE];
+    __shared__ int flag;
+    __shared__ int advanced;
+
+    // correspondence (r, workgroup, thread) -> index (r * grid + workgroup) * NTR + thread: every load
+    // instruction of a wave reads 64 consecutive doubles
+    double ru[R], rv[R], rx[R], ry[R], rz[R];
+    const int64_t first = (int64_t)blockIdx.x * NTR + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * NTR;
+    int mine = 0; // this thread holds correspondences r = 0 .. mine-1
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = first + r * step;
+        const bool ok = i < M;
+        const int64_t j = ok ? i : 0;
+        ru[r] = u[j];
+        rv[r] = v[j];
+        rx[r] = x[j];
+        ry[r] = y[j];
+        rz[r] = z[j];
+        mine += ok ? 1 : 0;
+    }
+    if (threadIdx.x < PICP_STATE_DOUBLES) st[threadIdx.x] = state[threadIdx.x];
+    if (threadIdx.x == 0) flag = 0;
+    __syncthreads();
+
+    unsigned epoch = 0;
+    while (st[ST_STOP] == 0.0) {
+        double T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = st[ST_C_T_W + i];
+        const double thr = st[ST_THR];
+        const bool all = (st[ST_MODE] != 0.0);
+        const int it = (int)st[ST_IT];
+
+        Stage1Sums a{0.0, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r < mine) stage1_point<PINHOLE>(T, cam, thr, ru[r], rv[r], rx[r], ry[r], rz[r], a);
+        {
+            const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
+            const double tot = block_sum<3, NTR>(vals, lds);
+            double g = 0.0;
+            if (!grid_total<3, 2>(tot, g, gx, epoch, lds, &flag)) return;
+            if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < 3) ? g : 0.0;
+            __syncthreads();
+        }
+        const double n1 = s1[S1_COUNT]; // identical in every workgroup, so the branch below is grid-uniform
+        if (n1 != 0.0) {
+            const double mean = s1[S1_SUM_CHI] / n1; // np.mean, src/ProjectiveICP.py:301
+            Stage2Sums s;
+            s.clear();
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r < mine) stage2_point<PINHOLE>(T, cam, thr, mean, all, ru[r], rv[r], rx[r], ry[r], rz[r], s);
+            double vals[S2_USED];
+            pack_sets(s, vals);
+            const double tot = block_sum<S2_USED, NTR>(vals, lds);
+            double g = 0.0;
+            if (!grid_total<S2_USED, 16>(tot, g, gx, epoch, lds, &flag)) return;
+            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = (threadIdx.x < S2_USED) ? g : 0.0;
+            __syncthreads();
+        } else {
+            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = 0.0; // :300
+            __syncthreads();
+        }
+
+        const bool record = (blockIdx.x == 0 && hist != nullptr && it < hist_rows);
+        if (threadIdx.x == 0) advanced = solve_and_schedule(st, s1, s2, sc, record ? row : nullptr, true) ? 1 : 0;
+        if (record && threadIdx.x >= 64 && threadIdx.x < 128) fill_history_linear(row, s1, s2, threadIdx.x - 64);
+        __syncthreads();
+        if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
+            hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < PICP_STATE_DOUBLES) state[threadIdx.x] = st[threadIdx.x];
+}
+
+static CameraK camera_of(const picp_camera* cam) {
+    CameraK c;
+    for (int i = 0; i < 9; ++i) c.k[i] = cam->K[i];
+    c.width = cam->width;
+    c.height = cam->height;
+    return c;
+}
+
+static int resident_grid(const picp_ctx* ctx) { return ctx->num_cus < MAX_GRID ? ctx->num_cus : MAX_GRID; }
+
+int64_t resident_capacity(const picp_ctx* ctx) {
+    const int64_t cap = (int64_t)resident_grid(ctx) * NTR * R_MAX;
+    return ctx->resident_limit < cap ? ctx->resident_limit : cap;
+}
+
+template <int R>
+static void launch_resident(picp_ctx* ctx, int grid, const double* u, const double* v, const double* x, const double* y,
+                            const double* z, int64_t M, double* state, const picp_camera* cam,
+                            const picp_schedule* sched, double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1) {
+    const CameraK c = camera_of(cam);
+    GridExchange gx{ctx->rslots, ctx->rfailed, ctx->resident_spin_limit};
+    auto kern = is_pinhole(cam->K) ? icp_resident_kernel<R, true> : icp_resident_kernel<R, false>;
+    if (e0 != nullptr)
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, c, *sched,
+                              gx, hist, hist_rows);
+    else
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, u, v, x, y, z, M, state, c, *sched, gx, hist,
+                           hist_rows);
+}
+
+// Enqueues the loop on an initialised state block.  Precondition: 0 < M <= resident_capacity(ctx).
+int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                     const double* z, int64_t M, double* state, const picp_camera* cam, const picp_schedule* sched,
+                     double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1) {
+    PICP_REQUIRE(M > 0 && M <= resident_capacity(ctx), "resident loop: %lld correspondences exceed the capacity",
+                 (long long)M);
+    // fewest correspondences per thread that still fit one workgroup per CU, then no more
+    // workgroups than that R needs
+    const int64_t lanes = (int64_t)resident_grid(ctx) * NTR;
+    const int64_t per_thread = (M + lanes - 1) / lanes;
+    const int R = per_thread <= 1 ? 1 : (per_thread <= 2 ? 2 : (per_thread <= 4 ? 4 : 8));
+    const int grid = (int)((M + (int64_t)NTR * R - 1) / ((int64_t)NTR * R));
+    PICP_REQUIRE(grid >= 1 && grid <= resident_grid(ctx), "resident loop: grid %d does not fit %d CUs", grid,
+                 resident_grid(ctx));
+    const int n = SLOTS * grid * RW;
+    hipLaunchKernelGGL(resident_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->rslots, n,
+                       ctx->rfailed);
+    switch (R) {
+    case 1: launch_resident<1>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
+    case 2: launch_resident<2>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
+    case 4: launch_resident<4>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
+    default: launch_resident<8>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
+    }
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+} // namespace picp

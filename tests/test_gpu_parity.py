@@ -25,6 +25,15 @@ def ctx():
     return pkg.get_context(0)
 
 
+@pytest.fixture(params=["streaming", "resident"])
+def loop_path(request, ctx):
+    """picp_run's two device paths: per-iteration stage launches that stream the arrays, and the
+    single launch that keeps the correspondences in registers."""
+    ctx.set_resident_limit(0 if request.param == "streaming" else None)
+    yield request.param
+    ctx.set_resident_limit(None)
+
+
 def yaml_sched(num_iterations=250, disable_stop=False, **over):
     p = dict(min_inliers=10, kernel_threshold=1000, min_kernel_threshold=10, max_kernel_threshold=2000,
              damping=64, min_damping=1, max_damping=64)
@@ -124,7 +133,9 @@ def test_linearize_edge_cases(ctx):
 
 
 @pytest.mark.parametrize("path", ["kernels", "workgroup"])
-def test_full_loop_reference_synthetic(ctx, path):
+def test_full_loop_reference_synthetic(ctx, path, loop_path):
+    if path == "workgroup" and loop_path == "resident":
+        pytest.skip("the batched kernel has one device path")
     g = load_golden("ref_synthetic.npz")
     cam = bundled_cam()
     for li in range(int(g["n_loops"])):
@@ -160,9 +171,9 @@ def _gtmap_problems(bundled, g):
     return uvs, pws
 
 
-def test_gtmap_icp_120_frames_kernel_path(ctx, bundled):
-    """The reference loop's 1 574 iterations on the bundled measurements (ground-truth map), launched
-    as stage-1 / stage-2 / solve kernels per iteration."""
+def test_gtmap_icp_120_frames_kernel_path(ctx, bundled, loop_path):
+    """The reference loop's 1 574 iterations on the bundled measurements (ground-truth map) through
+    picp_run: stage-1 / stage-2 / solve kernels per iteration, or the single-launch loop."""
     g = load_golden("ref_gtmap_icp.npz")
     cam, sched = bundled_cam(), yaml_sched()
     offs = g["iter_offsets"]
@@ -237,9 +248,12 @@ def test_association_sizes_and_duplicates(ctx):
     assert e1.numel() == 0 and e2.numel() == 0
 
 
-def test_large_loop_against_oracle(ctx):
-    """2^20 correspondences, 6 iterations: counts exact, H/b/T within 1e-9 of the numpy oracle."""
-    M = 1 << 20
+@pytest.mark.parametrize("M", [1 << 20, 300_001, 70_000])
+def test_large_loop_against_oracle(ctx, loop_path, M):
+    """Up to 2^20 correspondences, 6 iterations: counts exact, H/b/T within 1e-9 of the numpy oracle.
+    The sizes put 8, 4 (ragged) and 1 correspondences per thread into the single-launch loop."""
+    if loop_path == "resident":
+        assert M <= ctx.resident_capacity()
     uv, pw, _ = make_problem(M, seed=0)
     params = po.IcpParams(num_iterations=6, disable_stop=True)
     T_ref, valid_ref, h_ref = po.projective_icp(uv, pw, np.eye(4), params, record_linear=True)
