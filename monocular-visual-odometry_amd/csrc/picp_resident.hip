@@ -54,6 +54,15 @@ struct GridExchange {
     unsigned spin_limit; // re-reads before a waiting thread gives up
 };
 
+// A workgroup-uniform double as a scalar-register value: the loop's pose, threshold and mean are
+// read from LDS (vector registers); broadcasting lane 0's copy lets the compiler keep them in scalar
+// registers for the whole stage instead of 2 vector registers each.
+__device__ __forceinline__ double uniform(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == SENTINEL_BITS; }
 
 // First launch step: every record of every slot holds the sentinel.
@@ -125,6 +134,53 @@ __device__ __forceinline__ bool grid_total(double mine, double& out, const GridE
     return *lds_flag == 0;
 }
 
+// Stage 1 of one correspondence (as stage1_point) that also leaves what stage 2 needs of it in
+// `keep`: chi (NaN when the pair is outside the image or above the threshold, so that every later
+// comparison with it is false) and 1 / (K p)_z, the one division of the projection.
+template <bool PINHOLE>
+__device__ __forceinline__ void stage1_keep(const double* __restrict__ T, const CameraK& cam, double thr, double mu,
+                                            double mv, double x, double y, double z, Stage1Sums& s, double (&keep)[2]) {
+    const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
+    const double e0 = mu - p.u, e1 = mv - p.v;         // src/ProjectiveICP.py:333
+    const double chi = e0 * e0 + e1 * e1;              // :293
+    const bool in1 = p.inside && (chi <= thr);         // :290, :294
+    s.n_inside += p.inside ? 1u : 0u;
+    s.n1 += in1 ? 1u : 0u;
+    s.sum_chi += in1 ? chi : 0.0;
+    keep[0] = in1 ? chi : __builtin_nan("");
+    keep[1] = p.zi;
+}
+
+// Stage 2 of a correspondence that stage 1 accepted, from the kept values: the camera-frame point,
+// K p and the pixel are formed again with the expressions of project_point and the kept
+// reciprocal (an accepted pair is finite and in the image, where the pinhole and the general
+// product with K agree and the reciprocal form of the division is the one project_point used).
+template <bool PINHOLE>
+__device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const CameraK& cam, double mu, double mv,
+                                            double x, double y, double z, double chi, double zi, Stage2Sums& s) {
+    Projected p;
+    p.pcx = T[0] * x + T[1] * y + T[2] * z + T[3];
+    p.pcy = T[4] * x + T[5] * y + T[6] * z + T[7];
+    p.pcz = T[8] * x + T[9] * y + T[10] * z + T[11];
+    if (PINHOLE) {
+        p.h0 = cam.k[0] * p.pcx + cam.k[2] * p.pcz;
+        p.h1 = cam.k[4] * p.pcy + cam.k[5] * p.pcz;
+        p.h2 = cam.k[8] * p.pcz;
+    } else {
+        p.h0 = cam.k[0] * p.pcx + cam.k[1] * p.pcy + cam.k[2] * p.pcz;
+        p.h1 = cam.k[3] * p.pcx + cam.k[4] * p.pcy + cam.k[5] * p.pcz;
+        p.h2 = cam.k[6] * p.pcx + cam.k[7] * p.pcy + cam.k[8] * p.pcz;
+    }
+    const double e0 = mu - div_with_recip(p.h0, p.h2, zi);
+    const double e1 = mv - div_with_recip(p.h1, p.h2, zi);
+    p.zi = zi;
+    double J0[6], J1[6];
+    jacobian_rows<PINHOLE>(p, cam, J0, J1);
+    s.S.add<PINHOLE>(J0, J1, e0, e1);
+    s.chi += chi;
+    s.n += 1u;
+}
+
 template <int R, bool PINHOLE>
 __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                           const double* __restrict__ x, const double* __restrict__ y,
@@ -138,10 +194,16 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     __shared__ double row[PICP_HIST_STRIDE];
     __shared__ int flag;
     __shared__ int advanced;
+    // Dynamic LDS, thread-private columns (conflict-free): the measurements u, v as [R][2][NTR]
+    // (they are only read, once or twice per iteration, so they need not occupy registers) and the
+    // stage-1 results kept for stage 2 (chi, 1/z) as [R][2][NTR].
+    extern __shared__ double dyn[];
+    double* muv = dyn;
+    double* kept = dyn + R * 2 * NTR;
 
     // correspondence (r, workgroup, thread) -> index (r * grid + workgroup) * NTR + thread: every load
     // instruction of a wave reads 64 consecutive doubles
-    double ru[R], rv[R], rx[R], ry[R], rz[R];
+    double rx[R], ry[R], rz[R];
     const int64_t first = (int64_t)blockIdx.x * NTR + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * NTR;
     int mine = 0; // this thread holds correspondences r = 0 .. mine-1
@@ -150,8 +212,8 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         const int64_t i = first + r * step;
         const bool ok = i < M;
         const int64_t j = ok ? i : 0;
-        ru[r] = u[j];
-        rv[r] = v[j];
+        muv[(r * 2 + 0) * NTR + threadIdx.x] = u[j];
+        muv[(r * 2 + 1) * NTR + threadIdx.x] = v[j];
         rx[r] = x[j];
         ry[r] = y[j];
         rz[r] = z[j];
@@ -165,15 +227,21 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     while (st[ST_STOP] == 0.0) {
         double T[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) T[i] = st[ST_C_T_W + i];
-        const double thr = st[ST_THR];
+        for (int i = 0; i < 12; ++i) T[i] = uniform(st[ST_C_T_W + i]);
+        const double thr = uniform(st[ST_THR]);
         const bool all = (st[ST_MODE] != 0.0);
         const int it = (int)st[ST_IT];
 
         Stage1Sums a{0.0, 0u, 0u};
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (r < mine) stage1_point<PINHOLE>(T, cam, thr, ru[r], rv[r], rx[r], ry[r], rz[r], a);
+            if (r < mine) {
+                double keep[2];
+                stage1_keep<PINHOLE>(T, cam, thr, muv[(r * 2 + 0) * NTR + threadIdx.x],
+                                     muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], a, keep);
+                kept[(r * 2 + 0) * NTR + threadIdx.x] = keep[0];
+                kept[(r * 2 + 1) * NTR + threadIdx.x] = keep[1];
+            }
         {
             const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
             const double tot = block_sum<3, NTR>(vals, lds);
@@ -184,12 +252,19 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         }
         const double n1 = s1[S1_COUNT]; // identical in every workgroup, so the branch below is grid-uniform
         if (n1 != 0.0) {
-            const double mean = s1[S1_SUM_CHI] / n1; // np.mean, src/ProjectiveICP.py:301
+            const double mean = uniform(s1[S1_SUM_CHI] / n1); // np.mean, src/ProjectiveICP.py:301
             Stage2Sums s;
             s.clear();
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (r < mine) stage2_point<PINHOLE>(T, cam, thr, mean, all, ru[r], rv[r], rx[r], ry[r], rz[r], s);
+                if (r < mine) {
+                    const double chi = kept[(r * 2 + 0) * NTR + threadIdx.x];
+                    // NaN (rejected by stage 1) fails both tests; `all`: the stage-1 set, else chi < mean (:302)
+                    if ((chi <= thr) && (all || chi < mean))
+                        stage2_kept<PINHOLE>(T, cam, muv[(r * 2 + 0) * NTR + threadIdx.x],
+                                             muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], chi,
+                                             kept[(r * 2 + 1) * NTR + threadIdx.x], s);
+                }
             double vals[S2_USED];
             pack_sets(s, vals);
             const double tot = block_sum<S2_USED, NTR>(vals, lds);
@@ -234,12 +309,22 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
     const CameraK c = camera_of(cam);
     GridExchange gx{ctx->rslots, ctx->rfailed, ctx->resident_spin_limit};
     auto kern = is_pinhole(cam->K) ? icp_resident_kernel<R, true> : icp_resident_kernel<R, false>;
+    constexpr unsigned kept_bytes = R * 4 * NTR * sizeof(double); // u, v, chi, 1/z per correspondence
+    if (kept_bytes > 48 * 1024) { // above the default dynamic-LDS allowance: raise it once per kernel
+        static bool raised[2] = {false, false};
+        const int which = is_pinhole(cam->K) ? 1 : 0;
+        if (!raised[which]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kept_bytes);
+            raised[which] = true;
+        }
+    }
     if (e0 != nullptr)
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, c, *sched,
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, c, *sched,
                               gx, hist, hist_rows);
     else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, u, v, x, y, z, M, state, c, *sched, gx, hist,
-                           hist_rows);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, u, v, x, y, z, M, state, c, *sched, gx,
+                           hist, hist_rows);
 }
 
 // Enqueues the loop on an initialised state block.  Precondition: 0 < M <= resident_capacity(ctx).
