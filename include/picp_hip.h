@@ -124,6 +124,10 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
  * capacity is a property of the device (CUs x threads x registers). */
 int picp_set_resident_limit(picp_ctx* ctx, int64_t max_correspondences);
 int64_t picp_resident_capacity(picp_ctx* ctx);
+/* The single launch waits for all of its workgroups at every exchange, with a bound on each wait.  If
+ * the device is shared and part of the grid is not scheduled, the launch gives up and picp_run
+ * repeats the loop with the streaming kernels; this returns how often that has happened on ctx. */
+int picp_resident_aborts(picp_ctx* ctx);
 /* Timing aid for benchmarks: runs the single-launch loop `reps` times from w_T_c0_host, each launch
  * bracketed by HIP events bound to that dispatch, and reports the mean and minimum kernel duration
  * in milliseconds.  M must not exceed picp_resident_capacity.  Synchronises. */

@@ -67,6 +67,7 @@ _SIGNATURES = {
                            C.POINTER(ScheduleStruct), _P, _P, C.c_int32, C.POINTER(ResultStruct)]),
     "picp_set_resident_limit": (C.c_int, [_P, C.c_int64]),
     "picp_resident_capacity": (C.c_int64, [_P]),
+    "picp_resident_aborts": (C.c_int, [_P]),
     "picp_profile_run": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
                                    C.POINTER(ScheduleStruct), _P, C.c_int32, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
@@ -231,6 +232,10 @@ class Context:
 
     def resident_capacity(self):
         return int(self.lib.picp_resident_capacity(self.handle))
+
+    def resident_aborts(self):
+        """Single-launch loops that gave up at a grid-wide wait and were repeated with the streaming kernels."""
+        return int(self.lib.picp_resident_aborts(self.handle))
 
     def run(self, corr, w_T_c0, cam: CameraStruct, sched: ScheduleStruct, want_history=True):
         """picp_run on device arrays corr = [u, v, x, y, z].  Returns (ResultStruct, history ndarray)."""

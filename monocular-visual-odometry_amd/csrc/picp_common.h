@@ -30,7 +30,6 @@ struct picp_ctx {
     double* pinned; // host-pinned staging for small read-backs
     // register-resident loop (picp_resident.hip)
     double* rslots;                // [3][num_cus][PICP_S2_DOUBLES] exchange records
-    unsigned* rfailed;             // set by a launch that gave up at a grid-wide wait
     int64_t resident_limit;        // largest M the resident loop is used for (0: never)
     unsigned resident_spin_limit;  // polls before a waiting workgroup abandons the launch
     int resident_aborts;           // launches abandoned so far (each was repeated with the streaming kernels)
@@ -54,8 +53,8 @@ int hip_fail(hipError_t e, const char* what);
 // picp_resident.hip
 int64_t resident_capacity(const picp_ctx* ctx);
 int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
-                     const double* z, int64_t M, double* state, const picp_camera* cam, const picp_schedule* sched,
-                     double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1);
+                     const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
+                     const picp_schedule* sched, double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1);
 
 struct DeviceGuard {
     int prev = -1;

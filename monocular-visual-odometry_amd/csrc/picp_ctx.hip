@@ -67,10 +67,10 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, sizeof(double) * PINNED_DOUBLES, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemset(ctx->scratch, 0, sizeof(double) * SCR_DOUBLES);
     if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * 3 * PICP_S2_DOUBLES * ctx->num_cus);
-    if (e == hipSuccess) e = hipMalloc(&ctx->rfailed, sizeof(unsigned));
     ctx->resident_limit = INT64_MAX; // i.e. whatever fits (resident_capacity)
     ctx->resident_spin_limit = 1u << 18;
     if (const char* er = getenv("PICP_RESIDENT")) { if (atoi(er) == 0) ctx->resident_limit = 0; }
+    if (const char* es = getenv("PICP_RESIDENT_SPIN_LIMIT")) { int k = atoi(es); if (k >= 0) ctx->resident_spin_limit = (unsigned)k; }
     if (e != hipSuccess) {
         picp_destroy(ctx);
         return hip_fail(e, "picp_create allocations");
@@ -88,7 +88,6 @@ int picp_destroy(picp_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->rslots) (void)hipFree(ctx->rslots);
-    if (ctx->rfailed) (void)hipFree(ctx->rfailed);
     if (ctx->assoc_count) (void)hipFree(ctx->assoc_count);
     if (ctx->assoc_first) (void)hipFree(ctx->assoc_first);
     if (ctx->assoc_offset) (void)hipFree(ctx->assoc_offset);
@@ -112,6 +111,8 @@ int picp_set_resident_limit(picp_ctx* ctx, int64_t max_correspondences) {
 }
 
 int64_t picp_resident_capacity(picp_ctx* ctx) { return ctx ? resident_capacity(ctx) : 0; }
+
+int picp_resident_aborts(picp_ctx* ctx) { return ctx ? ctx->resident_aborts : 0; }
 
 int picp_synchronize(picp_ctx* ctx) {
     PICP_REQUIRE(ctx != nullptr, "picp_synchronize: null ctx");

@@ -475,6 +475,7 @@ int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const doub
                      double* state, int32_t reps, double* mean_ms, double* min_ms) {
     PICP_REQUIRE(ctx && cam && sched && state && mean_ms && min_ms && reps > 0, "picp_profile_run: bad argument");
     if (int rc = check_corr(u, v, x, y, z, M)) return rc;
+    if (int rc = check_pose(w_T_c0_host)) return rc;
     PICP_REQUIRE(M > 0 && M <= resident_capacity(ctx), "picp_profile_run: %lld correspondences do not fit the "
                  "single-launch loop (capacity %lld)", (long long)M, (long long)resident_capacity(ctx));
     DeviceGuard g(ctx->device);
@@ -484,8 +485,7 @@ int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const doub
     double sum = 0.0, best = 1e30;
     int rc = PICP_OK;
     for (int r = 0; r < reps && rc == PICP_OK; ++r) {
-        rc = picp_state_init(ctx, state, w_T_c0_host, sched);
-        if (rc == PICP_OK) rc = enqueue_resident(ctx, u, v, x, y, z, M, state, cam, sched, nullptr, 0, e0, e1);
+        rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, nullptr, 0, e0, e1);
         if (rc != PICP_OK) break;
         hipError_t e = hipEventSynchronize(e1);
         float ms = 0.f;
@@ -557,20 +557,20 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
     PICP_REQUIRE(sched->num_iterations >= 0, "picp_run: negative num_iterations");
     PICP_REQUIRE(hist == nullptr || hist_rows >= sched->num_iterations,
                  "picp_run: history has %d rows, num_iterations is %d", hist_rows, sched->num_iterations);
-    if (int rc = picp_state_init(ctx, state, w_T_c0_host, sched)) return rc;
+    if (int rc = check_pose(w_T_c0_host)) return rc;
+    if (int rc = check_corr(u, v, x, y, z, M)) return rc;
     DeviceGuard g(ctx->device);
     // Inputs that fit the register files run the whole loop in one launch (picp_resident.hip).
     if (M > 0 && M <= resident_capacity(ctx) && sched->num_iterations > 0) {
-        if (int rc = enqueue_resident(ctx, u, v, x, y, z, M, state, cam, sched, hist, (int)hist_rows, nullptr, nullptr))
+        if (int rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
+                                      nullptr, nullptr))
             return rc;
-        unsigned* failed = reinterpret_cast<unsigned*>(ctx->pinned + PICP_STATE_DOUBLES);
-        PICP_HIP_CHECK(hipMemcpyAsync(failed, ctx->rfailed, sizeof(*failed), hipMemcpyDeviceToHost, ctx->stream));
         if (int rc = picp_finish(ctx, state, hist, hist_rows, w_T_c0_host, result)) return rc; // synchronises
-        if (*failed == 0u) return PICP_OK;
+        if (ctx->pinned[ST_STOP] != 0.0) return PICP_OK; // picp_finish left the state block in ctx->pinned
         // the launch was abandoned at a grid-wide wait (device shared with other work): start over
         ctx->resident_aborts += 1;
-        if (int rc = picp_state_init(ctx, state, w_T_c0_host, sched)) return rc;
     }
+    if (int rc = picp_state_init(ctx, state, w_T_c0_host, sched)) return rc;
     // Rounds of {stage 1, stage 2, solve} are enqueued in chunks; between chunks the stop flag is
     // read back, so a loop that converged after a few iterations does not pay for launches that
     // would do nothing (every kernel returns at once when the flag is set, so overshooting is

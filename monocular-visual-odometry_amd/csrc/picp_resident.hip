@@ -50,7 +50,6 @@ constexpr unsigned long long SENTINEL_BITS = 0xFFF8C0DEC0DE5EEDull; // a NaN pay
 
 struct GridExchange {
     double* slots;       // [SLOTS][gridDim.x][RW]
-    unsigned* failed;    // set to 1 by a workgroup that gave up waiting
     unsigned spin_limit; // re-reads before a waiting thread gives up
 };
 
@@ -65,11 +64,17 @@ __device__ __forceinline__ double uniform(double v) {
 
 __device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == SENTINEL_BITS; }
 
-// First launch step: every record of every slot holds the sentinel.
-__global__ void resident_prepare_kernel(double* slots, int n, unsigned* failed) {
+struct StartPose {
+    double m[16];
+};
+
+// First launch step: every record of every slot holds the sentinel, and the state block holds the
+// loop entry state (src/ProjectiveICP.py:157-171).
+__global__ void resident_prepare_kernel(double* slots, int n, double* state, StartPose pose, double thr, double lambda,
+                                        int num_iterations) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) slots[i] = __longlong_as_double((long long)SENTINEL_BITS);
-    if (i == 0) *failed = 0u;
+    if (i == 0) init_state(state, pose.m, thr, lambda, num_iterations);
 }
 
 // Grid-wide sum of NV values.  `mine`: this workgroup's total of value tid (threads tid < NV).
@@ -115,7 +120,6 @@ __device__ __forceinline__ bool grid_total(double mine, double& out, const GridE
         if (!missing) break;
         if (++spins > gx.spin_limit) {
             *lds_flag = 1;
-            __hip_atomic_store(gx.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -307,7 +311,7 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
                             const double* z, int64_t M, double* state, const picp_camera* cam,
                             const picp_schedule* sched, double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1) {
     const CameraK c = camera_of(cam);
-    GridExchange gx{ctx->rslots, ctx->rfailed, ctx->resident_spin_limit};
+    GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
     auto kern = is_pinhole(cam->K) ? icp_resident_kernel<R, true> : icp_resident_kernel<R, false>;
     constexpr unsigned kept_bytes = R * 4 * NTR * sizeof(double); // u, v, chi, 1/z per correspondence
     if (kept_bytes > 48 * 1024) { // above the default dynamic-LDS allowance: raise it once per kernel
@@ -327,10 +331,12 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
                            hist, hist_rows);
 }
 
-// Enqueues the loop on an initialised state block.  Precondition: 0 < M <= resident_capacity(ctx).
+// Enqueues loop entry (state block from w_T_c0_host) and the loop.  Precondition:
+// 0 < M <= resident_capacity(ctx).  A launch that gave up at a grid-wide wait leaves the state's
+// stop flag clear (the final state is only written by a loop that ran to its end).
 int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
-                     const double* z, int64_t M, double* state, const picp_camera* cam, const picp_schedule* sched,
-                     double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1) {
+                     const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
+                     const picp_schedule* sched, double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1) {
     PICP_REQUIRE(M > 0 && M <= resident_capacity(ctx), "resident loop: %lld correspondences exceed the capacity",
                  (long long)M);
     // fewest correspondences per thread that still fit one workgroup per CU, then no more
@@ -342,8 +348,10 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     PICP_REQUIRE(grid >= 1 && grid <= resident_grid(ctx), "resident loop: grid %d does not fit %d CUs", grid,
                  resident_grid(ctx));
     const int n = SLOTS * grid * RW;
-    hipLaunchKernelGGL(resident_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->rslots, n,
-                       ctx->rfailed);
+    StartPose pose;
+    memcpy(pose.m, w_T_c0_host, sizeof(pose.m));
+    hipLaunchKernelGGL(resident_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->rslots, n, state,
+                       pose, sched->kernel_threshold, sched->damping, sched->num_iterations);
     switch (R) {
     case 1: launch_resident<1>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
     case 2: launch_resident<2>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
