@@ -11,16 +11,22 @@ import collections
 import csv
 import glob
 import json
+import sqlite3
 import sys
 
 
 def per_kernel(directory, counter):
-    files = glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True)
+    """Per-launch counter values by kernel, from rocprofv3's CSV output or its default rocpd database."""
     agg = collections.defaultdict(list)
-    for f in files:
+    for f in glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    for f in glob.glob(f"{directory}/**/*.db", recursive=True):
+        db = sqlite3.connect(f)
+        for name, value in db.execute("select kernel_name, value from counters_collection where counter_name = ?",
+                                      (counter,)):
+            agg[name.split("(")[0].replace("void ", "")].append(float(value))
     return {k: {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in agg.items()}
 
 
@@ -29,6 +35,12 @@ def main():
     if mode == "stats":
         for f in glob.glob(f"{sys.argv[2]}/**/*kernel_stats.csv", recursive=True):
             sys.stdout.write(open(f).read())
+        for f in glob.glob(f"{sys.argv[2]}/**/*.db", recursive=True):
+            w = csv.writer(sys.stdout)
+            w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
+            for row in sqlite3.connect(f).execute(
+                    "select name, total_calls, total_duration, average, percentage from top_kernels"):
+                w.writerow(row)
     elif mode == "pmc":
         fetch, write = per_kernel(sys.argv[2], "FETCH_SIZE"), per_kernel(sys.argv[3], "WRITE_SIZE")
         out = {"units": "FETCH_SIZE / WRITE_SIZE in KiB per launch; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
