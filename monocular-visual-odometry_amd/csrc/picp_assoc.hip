@@ -7,17 +7,23 @@
 // words (+0.0 and -0.0 differ only in the high word, and NaN is excluded by the full test), so
 // each pair is first screened with one 32-bit integer compare of component 0's low word; only
 // the pairs that pass (true matches plus a 2^-32 fraction of the rest) get the full float
-// comparison of all D components.  Set-2 screening keys are staged through LDS in tiles and read
-// back as 16-byte broadcasts; each lane screens R query rows against every key it reads.
+// comparison of all D components.  Set-2 screening keys reach the compares as scalar operands;
+// each lane screens R query rows against every key.
+#include <stdlib.h>
+
 #include "picp_common.h"
 #include "picp_device.h"
 
 namespace picp {
 
 constexpr int ANT = 256;        // threads per workgroup
-constexpr int TILE = 4096;      // set-2 keys per LDS tile (16 KiB)
 constexpr int SCAN_ITEMS = 4;   // prefix-sum elements per thread
 constexpr int SCAN_BLOCK = ANT * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t m = a < b ? a : b;
+    return m < c ? m : c; // v_min3_u32
+}
 
 __device__ __forceinline__ uint32_t low_word(double d) { return (uint32_t)__double_as_longlong(d); }
 
@@ -36,12 +42,18 @@ __device__ __forceinline__ bool rows_equal(const double* __restrict__ a, const d
 }
 
 // For each query row i: number of equal rows of set 2 and the first of them.
+//
+// The screening keys of set 2 are the same for every lane, so they are fetched with scalar loads
+// (eight keys per step, the next step's keys requested before the current ones are compared) and
+// enter the compares as scalar operands: per pair one v_cmp_eq_u32 into a lane mask and one scalar
+// OR, nothing else -- no LDS staging, no barriers.  A lane screens R query rows per key.  Only when
+// some lane of the wave hits within a step does the wave look at that step's keys one by one.
+// key2 must be readable up to index round_up(N2, 8) + 7 (the workspace is over-allocated).
 template <int R>
 __global__ __launch_bounds__(ANT) void assoc_scan_kernel(const double* __restrict__ app1, int64_t N1,
                                                          const double* __restrict__ app2, int64_t N2, int D,
                                                          const uint32_t* __restrict__ key2,
                                                          int64_t* __restrict__ count, int64_t* __restrict__ first) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[TILE];
     uint32_t qk[R];
     int64_t qi[R];
     int64_t cnt[R];
@@ -53,29 +65,44 @@ __global__ __launch_bounds__(ANT) void assoc_scan_kernel(const double* __restric
         cnt[r] = 0;
         fst[r] = -1;
     }
-    for (int64_t t0 = 0; t0 < N2; t0 += TILE) {
-        const int lim = (int)((N2 - t0 < TILE) ? (N2 - t0) : TILE);
-        __syncthreads();
-        for (int k = threadIdx.x; k < TILE; k += ANT) tile[k] = (k < lim) ? key2[t0 + k] : 0u;
-        __syncthreads();
-        const int lim4 = (lim + 3) & ~3;
-        for (int k = 0; k < lim4; k += 4) {
-            const uint4 kk = *reinterpret_cast<const uint4*>(&tile[k]);
-            bool hit = false;
+    const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(key2);
+    uint4 na = keys4[0], nb = keys4[1];
+    for (int64_t k = 0; k < N2; k += 8) {
+        const uint4 a = na, b = nb;
+        // Scalar loads return out of order, so a wave can only wait for all of them: make the wait
+        // for this step's keys happen here, before the next step's keys are requested, so that
+        // request stays in flight during the compares.
+        asm volatile("" ::"s"(a.x), "s"(a.w), "s"(b.x), "s"(b.w));
+        na = keys4[(k >> 2) + 2]; // uniform address: s_load
+        nb = keys4[(k >> 2) + 3];
+        // Screening in vector registers only: acc = min over the step's keys of (query key XOR key),
+        // which is zero exactly when one of them is equal.  Twelve vector instructions per eight
+        // pairs (8 v_xor + 4 v_min3) and no lane masks: a compare per pair would need a scalar OR
+        // per pair as well, and the CU's single scalar unit cannot keep up with four SIMDs of them.
+        uint32_t any = 0xffffffffu;
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                hit = hit | (qk[r] == kk.x) | (qk[r] == kk.y) | (qk[r] == kk.z) | (qk[r] == kk.w);
-            if (hit) {
+        for (int r = 0; r < R; ++r) {
+            uint32_t acc = umin3(qk[r] ^ a.x, qk[r] ^ a.y, qk[r] ^ a.z);
+            acc = umin3(acc, qk[r] ^ a.w, qk[r] ^ b.x);
+            acc = umin3(acc, qk[r] ^ b.y, qk[r] ^ b.z);
+            any = umin3(any, acc, qk[r] ^ b.w);
+        }
+        const bool hit = (any == 0u);
+        if (hit) {
+            const uint32_t kk[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (qi[r] >= N1) continue;
+            for (int r = 0; r < R; ++r) {
+                if (qi[r] >= N1) continue;
+                // an opaque copy of the query key: otherwise the compiler keeps all 8 R lane masks of
+                // the screening step alive for reuse here and spills scalar registers in the hot loop
+                uint32_t q = qk[r];
+                asm volatile("" : "+v"(q));
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int64_t j = t0 + k + c;
-                        if (j < N2 && qk[r] == tile[k + c] && rows_equal(app1 + qi[r] * D, app2 + j * D, D)) {
-                            if (cnt[r] == 0) fst[r] = j;
-                            cnt[r] += 1;
-                        }
+                for (int c = 0; c < 8; ++c) {
+                    const int64_t j = k + c;
+                    if (j < N2 && q == kk[c] && rows_equal(app1 + qi[r] * D, app2 + j * D, D)) {
+                        if (cnt[r] == 0) fst[r] = j;
+                        cnt[r] += 1;
                     }
                 }
             }
@@ -270,10 +297,17 @@ int picp_associate(picp_ctx* ctx, const double* app1, int64_t N1, const double* 
     hipStream_t s = ctx->stream;
     hipLaunchKernelGGL(assoc_keys_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, (int)D,
                        ctx->assoc_key);
-    // Few query rows: one per lane keeps more workgroups busy; many: four per lane amortise the
-    // LDS reads of the screening keys.
-    if (N1 >= (int64_t)ANT * 4 * ctx->num_cus) {
+    // Few query rows: one per lane keeps more workgroups busy; many: eight per lane amortise the
+    // key fetches and the loop overhead.
+    int rows_per_lane = (N1 >= (int64_t)ANT * 8 * ctx->num_cus) ? 8 : 1;
+    if (const char* e = getenv("PICP_ASSOC_ROWS_PER_LANE")) rows_per_lane = atoi(e); // tuning override
+    if (rows_per_lane == 4) {
         constexpr int R = 4;
+        const int64_t nb = (N1 + (int64_t)ANT * R - 1) / ((int64_t)ANT * R);
+        hipLaunchKernelGGL(assoc_scan_kernel<R>, dim3((unsigned)nb), dim3(ANT), 0, s, app1, N1, app2, N2, (int)D,
+                           (const uint32_t*)ctx->assoc_key, ctx->assoc_count, ctx->assoc_first);
+    } else if (rows_per_lane == 8) {
+        constexpr int R = 8;
         const int64_t nb = (N1 + (int64_t)ANT * R - 1) / ((int64_t)ANT * R);
         hipLaunchKernelGGL(assoc_scan_kernel<R>, dim3((unsigned)nb), dim3(ANT), 0, s, app1, N1, app2, N2, (int)D,
                            (const uint32_t*)ctx->assoc_key, ctx->assoc_count, ctx->assoc_first);
