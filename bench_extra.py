@@ -56,17 +56,19 @@ def main():
     app2 = rng.uniform(-1.0, 1.0, (n, 10))
     perm = rng.permutation(n)
     d1, d2 = ctx.to_device(app2[perm]), ctx.to_device(app2)
-    ctx.associate(d1, d2)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.reps):
-        i1, i2 = ctx.associate(d1, d2)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.reps
-    assert np.array_equal(i2.cpu().numpy(), perm)
-    print(json.dumps({"config": f"appearance association, {n} x {n} descriptors of 10 doubles, all pairs",
-                      "ms": dt * 1e3, "pair_evaluations_per_s": float(n) * n / dt}))
-
+    for mode, label in (("scan", "all pairs"), ("hash", "hash join")):
+        ctx.set_association_mode(mode)
+        ctx.associate(d1, d2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            i1, i2 = ctx.associate(d1, d2)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.reps
+        assert np.array_equal(i2.cpu().numpy(), perm)
+        print(json.dumps({"config": f"appearance association, {n} x {n} descriptors of 10 doubles, {label}",
+                          "ms": dt * 1e3, "pair_evaluations_per_s": float(n) * n / dt}))
+    ctx.set_association_mode("auto")
 
 if __name__ == "__main__":
     main()

@@ -193,6 +193,15 @@ int picp_linearize(picp_ctx* ctx, const double* u, const double* v, const double
  * written and PICP_ERR_CAPACITY is returned.  Synchronises. */
 int picp_associate(picp_ctx* ctx, const double* app1, int64_t N1, const double* app2, int64_t N2, int32_t D,
                    int64_t* idx1, int64_t* idx2, int64_t capacity, int64_t* count);
+/* picp_associate has two methods with identical output.  mode 1: the all-pairs scan, the reference's
+ * double loop (:29-30) with a 32-bit screening test per pair.  mode 2: a hash join -- set 2 goes into
+ * an open-addressing table keyed by a hash of the descriptor values, each query row runs the full
+ * comparison only against its bucket, matches are emitted in increasing set-2 row.  mode 0 (default):
+ * the join for large inputs (N1 * N2 >= 4e9), the scan otherwise.  The join gives up on inputs with
+ * long runs of equal rows (more than 32 equal set-2 rows for one query row) and the scan is run
+ * instead; picp_association_fallbacks counts how often. */
+int picp_set_association_mode(picp_ctx* ctx, int32_t mode);
+int picp_association_fallbacks(picp_ctx* ctx);
 
 /* Camera.project_point for N points (src/Camera.py:82-121): inside[N] (uint8, device) and the
  * projected pixel uv_u[N], uv_v[N] (device; written for every point, meaningful where inside).

@@ -87,6 +87,8 @@ _SIGNATURES = {
                                  C.POINTER(C.c_int64)]),
     "picp_associate": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64,
                                  C.POINTER(C.c_int64)]),
+    "picp_set_association_mode": (C.c_int, [_P, C.c_int32]),
+    "picp_association_fallbacks": (C.c_int, [_P]),
     "picp_project": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), _P, _P, _P]),
     "picp_gather_pairs": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "picp_invert_pose": (C.c_int, [_P, _P, _P]),
@@ -283,6 +285,14 @@ class Context:
         return H.reshape(6, 6), b, int(n.value), float(err.value), int(nin.value)
 
     # ---- association ---------------------------------------------------------------------------
+    def set_association_mode(self, mode="auto"):
+        """"auto": hash join for large inputs, all-pairs scan otherwise; "scan"; "hash"."""
+        check(self.lib.picp_set_association_mode(self.handle, {"auto": 0, "scan": 1, "hash": 2}[mode]),
+              "picp_set_association_mode")
+
+    def association_fallbacks(self):
+        return int(self.lib.picp_association_fallbacks(self.handle))
+
     def associate(self, app1, app2, capacity=None):
         """Device descriptor tensors [N1,D], [N2,D] -> (idx1, idx2) int64 device tensors, query-major order."""
         N1, N2 = int(app1.shape[0]), int(app2.shape[0])

@@ -117,6 +117,132 @@ __global__ __launch_bounds__(ANT) void assoc_scan_kernel(const double* __restric
     }
 }
 
+// ---- hash join: the same pairs without the all-pairs scan --------------------------------------
+// Equal rows have equal hashes, so each query row only needs the rows of set 2 in its hash bucket.
+// Set 2 goes into an open-addressing table (linear probing, at most half full); an entry is
+// (32-bit tag of the hash) << 32 | (row + 1), 0 = empty.  A query walks its probe sequence to the
+// first empty entry and runs the full comparison (rows_equal) on every entry whose tag matches, so
+// the set of pairs is exactly that of the all-pairs scan; within a query row the matches are
+// emitted in increasing set-2 row, which restores the reference's order (src/data_association.py:29-30)
+// whatever order the rows were inserted in.
+// The hash is taken over the descriptor's values, not its bytes: -0.0 and +0.0 compare equal and
+// are hashed alike; a row with a NaN component equals nothing (not even itself) and is left out.
+// Many equal rows make long probe sequences; a walk that exceeds HASH_MAX_PROBE entries, or a
+// query row with more than HASH_MAX_DUP matches, raises a flag and the host falls back to the
+// all-pairs scan, which has no such limit.
+constexpr int HASH_MAX_PROBE = 2048;
+constexpr int HASH_MAX_DUP = 32;
+
+// Returns false for a row that contains NaN.
+__device__ __forceinline__ bool row_hash(const double* __restrict__ row, int D, uint64_t* h_out) {
+    uint64_t h = 0x243f6a8885a308d3ull;
+    bool ok = true;
+    for (int d = 0; d < D; ++d) {
+        const double x = row[d];
+        ok = ok && (x == x);
+        const uint64_t bits = (x == 0.0) ? 0ull : (uint64_t)__double_as_longlong(x);
+        h = (h ^ bits) * 0x9e3779b97f4a7c15ull;
+        h ^= h >> 29;
+    }
+    h *= 0xbf58476d1ce4e5b9ull;
+    h ^= h >> 32;
+    *h_out = h;
+    return ok;
+}
+
+__global__ __launch_bounds__(ANT) void hash_build_kernel(const double* __restrict__ app2, int64_t N2, int D,
+                                                         unsigned long long* __restrict__ table, uint64_t mask,
+                                                         int* __restrict__ flag) {
+    const int64_t j = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    if (j >= N2) return;
+    uint64_t h;
+    if (!row_hash(app2 + j * D, D, &h)) return;
+    const unsigned long long entry = ((h >> 32) << 32) | (unsigned long long)(j + 1);
+    uint64_t slot = h & mask;
+    for (int probe = 0; probe < HASH_MAX_PROBE; ++probe) {
+        if (atomicCAS(&table[slot], 0ull, entry) == 0ull) return;
+        slot = (slot + 1) & mask;
+    }
+    atomicExch(flag, 1);
+}
+
+// Walks query row i's probe sequence; calls match(j) for every equal row j of set 2.
+// Returns false when the walk was cut short.
+template <typename F>
+__device__ __forceinline__ bool hash_walk(const double* __restrict__ q, const double* __restrict__ app2, int D,
+                                          const unsigned long long* __restrict__ table, uint64_t mask, uint64_t h,
+                                          F&& match) {
+    const unsigned long long tag = h >> 32;
+    uint64_t slot = h & mask;
+    for (int probe = 0; probe < HASH_MAX_PROBE; ++probe) {
+        const unsigned long long e = table[slot];
+        if (e == 0ull) return true;
+        if ((e >> 32) == tag) {
+            const int64_t j = (int64_t)(e & 0xffffffffull) - 1;
+            if (rows_equal(q, app2 + j * D, D)) match(j);
+        }
+        slot = (slot + 1) & mask;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(ANT) void hash_count_kernel(const double* __restrict__ app1, int64_t N1,
+                                                         const double* __restrict__ app2, int D,
+                                                         const unsigned long long* __restrict__ table, uint64_t mask,
+                                                         int64_t* __restrict__ count, int64_t* __restrict__ first,
+                                                         int* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    if (i >= N1) return;
+    int64_t cnt = 0, fst = -1;
+    uint64_t h;
+    if (row_hash(app1 + i * D, D, &h)) {
+        const bool complete = hash_walk(app1 + i * D, app2, D, table, mask, h, [&](int64_t j) {
+            fst = (cnt == 0 || j < fst) ? j : fst;
+            cnt += 1;
+        });
+        if (!complete || cnt > HASH_MAX_DUP) atomicExch(flag, 1);
+    }
+    count[i] = cnt;
+    first[i] = fst;
+}
+
+__global__ __launch_bounds__(ANT) void hash_emit_kernel(const double* __restrict__ app1, int64_t N1,
+                                                        const double* __restrict__ app2, int D,
+                                                        const unsigned long long* __restrict__ table, uint64_t mask,
+                                                        const int64_t* __restrict__ count,
+                                                        const int64_t* __restrict__ first,
+                                                        const int64_t* __restrict__ offset, int64_t* __restrict__ idx1,
+                                                        int64_t* __restrict__ idx2, int64_t capacity) {
+    const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    if (i >= N1) return;
+    const int64_t c = count[i];
+    if (c == 0) return;
+    const int64_t o = offset[i];
+    if (c == 1) {
+        if (o < capacity) {
+            idx1[o] = i;
+            idx2[o] = first[i];
+        }
+        return;
+    }
+    // several equal rows (at most HASH_MAX_DUP, or the host would not have come here): emit them in
+    // increasing row order by repeated selection of the next larger one
+    uint64_t h;
+    (void)row_hash(app1 + i * D, D, &h);
+    int64_t last = -1;
+    for (int64_t k = 0; k < c; ++k) {
+        int64_t best = INT64_MAX;
+        (void)hash_walk(app1 + i * D, app2, D, table, mask, h, [&](int64_t j) {
+            if (j > last && j < best) best = j;
+        });
+        if (o + k < capacity) {
+            idx1[o + k] = i;
+            idx2[o + k] = best;
+        }
+        last = best;
+    }
+}
+
 // ---- exclusive prefix sum of int64 counts ------------------------------------------------------
 __device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* lds /*ANT/64 + 1*/, int64_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -277,11 +403,101 @@ static int ensure_assoc_workspace(picp_ctx* ctx, int64_t N1, int64_t N2) {
     return PICP_OK;
 }
 
+static int ensure_hash_table(picp_ctx* ctx, int64_t entries) {
+    if (entries > ctx->assoc_table_cap) {
+        if (ctx->assoc_table) (void)hipFree(ctx->assoc_table);
+        ctx->assoc_table = nullptr;
+        ctx->assoc_table_cap = 0;
+        PICP_HIP_CHECK(hipMalloc(&ctx->assoc_table, sizeof(unsigned long long) * (entries + 1))); // + the flag word
+        ctx->assoc_table_cap = entries;
+    }
+    return PICP_OK;
+}
+
 } // namespace picp
 
 using namespace picp;
 
 extern "C" {
+
+int picp_set_association_mode(picp_ctx* ctx, int32_t mode) {
+    PICP_REQUIRE(ctx != nullptr, "picp_set_association_mode: null ctx");
+    PICP_REQUIRE(mode >= 0 && mode <= 2, "picp_set_association_mode: mode %d is not 0 (auto), 1 (all pairs) or 2 (hash join)",
+                 (int)mode);
+    ctx->assoc_mode = mode;
+    return PICP_OK;
+}
+
+// One pass of the association with the chosen method.  *retry is set when the hash join met more
+// equal rows than it handles and the caller should run the all-pairs scan instead.
+static int associate_pass(picp_ctx* ctx, bool hashed, const double* app1, int64_t N1, const double* app2, int64_t N2,
+                          int D, int64_t* idx1, int64_t* idx2, int64_t capacity, int64_t* count, bool* retry) {
+    hipStream_t s = ctx->stream;
+    *retry = false;
+    uint64_t mask = 0;
+    int* flag = nullptr;
+    const unsigned grid1 = (unsigned)((N1 + ANT - 1) / ANT);
+    if (hashed) {
+        uint64_t entries = 1024;
+        while (entries < 2 * (uint64_t)N2) entries <<= 1;
+        if (int rc = ensure_hash_table(ctx, (int64_t)entries)) return rc;
+        mask = entries - 1;
+        flag = reinterpret_cast<int*>(ctx->assoc_table + entries);
+        PICP_HIP_CHECK(hipMemsetAsync(ctx->assoc_table, 0, sizeof(unsigned long long) * (entries + 1), s));
+        hipLaunchKernelGGL(hash_build_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, D,
+                           ctx->assoc_table, mask, flag);
+        hipLaunchKernelGGL(hash_count_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, D,
+                           (const unsigned long long*)ctx->assoc_table, mask, ctx->assoc_count, ctx->assoc_first, flag);
+    } else {
+        hipLaunchKernelGGL(assoc_keys_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, D,
+                           ctx->assoc_key);
+        // Few query rows: one per lane keeps more workgroups busy; many: eight per lane amortise
+        // the key fetches and the loop overhead.
+        int rows_per_lane = (N1 >= (int64_t)ANT * 8 * ctx->num_cus) ? 8 : 1;
+        if (const char* e = getenv("PICP_ASSOC_ROWS_PER_LANE")) rows_per_lane = atoi(e); // tuning override
+        const int R = rows_per_lane == 8 ? 8 : (rows_per_lane == 4 ? 4 : 1);
+        const unsigned nb = (unsigned)((N1 + (int64_t)ANT * R - 1) / ((int64_t)ANT * R));
+        auto kern = R == 8 ? assoc_scan_kernel<8> : (R == 4 ? assoc_scan_kernel<4> : assoc_scan_kernel<1>);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(ANT), 0, s, app1, N1, app2, N2, D, (const uint32_t*)ctx->assoc_key,
+                           ctx->assoc_count, ctx->assoc_first);
+    }
+    PICP_HIP_CHECK(hipGetLastError());
+    const int64_t nb = (N1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count,
+                       N1, ctx->assoc_blocksum);
+    hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(ANT), 0, s, ctx->assoc_blocksum, nb);
+    hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count, N1,
+                       (const int64_t*)ctx->assoc_blocksum, nb, ctx->assoc_offset);
+    PICP_HIP_CHECK(hipGetLastError());
+    int64_t* h = reinterpret_cast<int64_t*>(ctx->pinned);
+    h[1] = 0;
+    PICP_HIP_CHECK(hipMemcpyAsync(h, ctx->assoc_offset + N1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (hashed) PICP_HIP_CHECK(hipMemcpyAsync(h + 1, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    PICP_HIP_CHECK(hipStreamSynchronize(s));
+    if (hashed && h[1] != 0) {
+        *retry = true;
+        return PICP_OK;
+    }
+    *count = h[0];
+    if (h[0] > capacity) {
+        set_error("picp_associate: %lld pairs found, index arrays hold %lld", (long long)h[0], (long long)capacity);
+        return PICP_ERR_CAPACITY;
+    }
+    if (h[0] > 0) {
+        if (hashed)
+            hipLaunchKernelGGL(hash_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, D,
+                               (const unsigned long long*)ctx->assoc_table, mask, (const int64_t*)ctx->assoc_count,
+                               (const int64_t*)ctx->assoc_first, (const int64_t*)ctx->assoc_offset, idx1, idx2,
+                               capacity);
+        else
+            hipLaunchKernelGGL(assoc_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, N2, D,
+                               (const int64_t*)ctx->assoc_count, (const int64_t*)ctx->assoc_first,
+                               (const int64_t*)ctx->assoc_offset, idx1, idx2, capacity);
+        PICP_HIP_CHECK(hipGetLastError());
+        PICP_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return PICP_OK;
+}
 
 int picp_associate(picp_ctx* ctx, const double* app1, int64_t N1, const double* app2, int64_t N2, int32_t D,
                    int64_t* idx1, int64_t* idx2, int64_t capacity, int64_t* count) {
@@ -294,53 +510,20 @@ int picp_associate(picp_ctx* ctx, const double* app1, int64_t N1, const double* 
     if (N1 == 0 || N2 == 0) return PICP_OK;
     DeviceGuard g(ctx->device);
     if (int rc = ensure_assoc_workspace(ctx, N1, N2)) return rc;
-    hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(assoc_keys_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, (int)D,
-                       ctx->assoc_key);
-    // Few query rows: one per lane keeps more workgroups busy; many: eight per lane amortise the
-    // key fetches and the loop overhead.
-    int rows_per_lane = (N1 >= (int64_t)ANT * 8 * ctx->num_cus) ? 8 : 1;
-    if (const char* e = getenv("PICP_ASSOC_ROWS_PER_LANE")) rows_per_lane = atoi(e); // tuning override
-    if (rows_per_lane == 4) {
-        constexpr int R = 4;
-        const int64_t nb = (N1 + (int64_t)ANT * R - 1) / ((int64_t)ANT * R);
-        hipLaunchKernelGGL(assoc_scan_kernel<R>, dim3((unsigned)nb), dim3(ANT), 0, s, app1, N1, app2, N2, (int)D,
-                           (const uint32_t*)ctx->assoc_key, ctx->assoc_count, ctx->assoc_first);
-    } else if (rows_per_lane == 8) {
-        constexpr int R = 8;
-        const int64_t nb = (N1 + (int64_t)ANT * R - 1) / ((int64_t)ANT * R);
-        hipLaunchKernelGGL(assoc_scan_kernel<R>, dim3((unsigned)nb), dim3(ANT), 0, s, app1, N1, app2, N2, (int)D,
-                           (const uint32_t*)ctx->assoc_key, ctx->assoc_count, ctx->assoc_first);
-    } else {
-        const int64_t nb = (N1 + ANT - 1) / ANT;
-        hipLaunchKernelGGL(assoc_scan_kernel<1>, dim3((unsigned)nb), dim3(ANT), 0, s, app1, N1, app2, N2, (int)D,
-                           (const uint32_t*)ctx->assoc_key, ctx->assoc_count, ctx->assoc_first);
-    }
-    PICP_HIP_CHECK(hipGetLastError());
-    const int64_t nb = (N1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count,
-                       N1, ctx->assoc_blocksum);
-    hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(ANT), 0, s, ctx->assoc_blocksum, nb);
-    hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count, N1,
-                       (const int64_t*)ctx->assoc_blocksum, nb, ctx->assoc_offset);
-    PICP_HIP_CHECK(hipGetLastError());
-    int64_t* h = reinterpret_cast<int64_t*>(ctx->pinned);
-    PICP_HIP_CHECK(hipMemcpyAsync(h, ctx->assoc_offset + N1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    PICP_HIP_CHECK(hipStreamSynchronize(s));
-    *count = h[0];
-    if (h[0] > capacity) {
-        set_error("picp_associate: %lld pairs found, index arrays hold %lld", (long long)h[0], (long long)capacity);
-        return PICP_ERR_CAPACITY;
-    }
-    if (h[0] > 0) {
-        hipLaunchKernelGGL(assoc_emit_kernel, dim3((unsigned)((N1 + ANT - 1) / ANT)), dim3(ANT), 0, s, app1, N1, app2,
-                           N2, (int)D, (const int64_t*)ctx->assoc_count, (const int64_t*)ctx->assoc_first,
-                           (const int64_t*)ctx->assoc_offset, idx1, idx2, capacity);
-        PICP_HIP_CHECK(hipGetLastError());
-        PICP_HIP_CHECK(hipStreamSynchronize(s));
-    }
-    return PICP_OK;
+    // Hash join when the all-pairs scan would be the slower of the two (it screens about 1.7e13
+    // pairs per second; the join costs a few tens of microseconds of launches plus ~1 ns per row).
+    const bool fits = N2 < (int64_t)0xfffffffe; // table entries hold 32-bit row numbers
+    PICP_REQUIRE(!(ctx->assoc_mode == 2 && !fits), "picp_associate: the hash join holds 32-bit row numbers");
+    const bool hashed = ctx->assoc_mode == 2 || (ctx->assoc_mode == 0 && fits && (double)N1 * (double)N2 >= 4.0e9);
+    bool retry = false;
+    if (int rc = associate_pass(ctx, hashed, app1, N1, app2, N2, (int)D, idx1, idx2, capacity, count, &retry)) return rc;
+    if (!retry) return PICP_OK;
+    // many equal rows: the all-pairs scan has no limit on them
+    ctx->assoc_hash_fallbacks += 1;
+    return associate_pass(ctx, false, app1, N1, app2, N2, (int)D, idx1, idx2, capacity, count, &retry);
 }
+
+int picp_association_fallbacks(picp_ctx* ctx) { return ctx ? ctx->assoc_hash_fallbacks : 0; }
 
 int picp_project(picp_ctx* ctx, const double* x, const double* y, const double* z, int64_t N,
                  const double* c_T_w_host, const picp_camera* cam, uint8_t* inside, double* uv_u, double* uv_v) {

@@ -27,6 +27,10 @@ struct picp_ctx {
     uint32_t* assoc_key;   // [key_cap] low words of component 0 of set 2
     int64_t assoc_cap;
     int64_t assoc_key_cap;
+    unsigned long long* assoc_table; // [table_cap + 1] hash-join table and its fallback flag
+    int64_t assoc_table_cap;
+    int assoc_mode;           // 0 auto, 1 all-pairs scan, 2 hash join
+    int assoc_hash_fallbacks; // hash joins abandoned for the all-pairs scan (heavy duplication)
     double* pinned; // host-pinned staging for small read-backs
     // register-resident loop (picp_resident.hip)
     double* rslots;                // [3][num_cus][PICP_S2_DOUBLES] exchange records

@@ -93,6 +93,7 @@ int picp_destroy(picp_ctx* ctx) {
     if (ctx->assoc_offset) (void)hipFree(ctx->assoc_offset);
     if (ctx->assoc_blocksum) (void)hipFree(ctx->assoc_blocksum);
     if (ctx->assoc_key) (void)hipFree(ctx->assoc_key);
+    if (ctx->assoc_table) (void)hipFree(ctx->assoc_table);
     delete ctx;
     return PICP_OK;
 }

@@ -74,10 +74,12 @@ def test_batched_4096_frames_of_2048_correspondences():
             assert rel_err(rr["T"][k], T_ref) < 1e-9, (k, n)
 
 
-def test_association_one_million_by_one_million():
+@pytest.mark.parametrize("mode", ["scan", "auto"])
+def test_association_one_million_by_one_million(mode):
     """Config 5: 10^6 x 10^6 ten-component descriptors, set 1 a permutation of set 2: the answer is the
-    inverse permutation, in query order."""
+    inverse permutation, in query order.  "scan" = all 10^12 pairs; "auto" picks the hash join here."""
     ctx = pkg.get_context(0)
+    ctx.set_association_mode(mode)
     n = 1_000_000
     rng = np.random.default_rng(7)
     app2 = rng.uniform(-1.0, 1.0, (n, 10))
@@ -87,6 +89,7 @@ def test_association_one_million_by_one_million():
     assert i1.numel() == n
     assert np.array_equal(i1.cpu().numpy(), np.arange(n))
     assert np.array_equal(i2.cpu().numpy(), perm)
+    ctx.set_association_mode("auto")
 
 
 def test_loop_invariances_at_full_size():

@@ -34,6 +34,14 @@ def loop_path(request, ctx):
     ctx.set_resident_limit(None)
 
 
+@pytest.fixture(params=["scan", "hash"])
+def assoc_mode(request, ctx):
+    """picp_associate's two methods: the all-pairs scan and the hash join."""
+    ctx.set_association_mode(request.param)
+    yield request.param
+    ctx.set_association_mode("auto")
+
+
 def yaml_sched(num_iterations=250, disable_stop=False, **over):
     p = dict(min_inliers=10, kernel_threshold=1000, min_kernel_threshold=10, max_kernel_threshold=2000,
              damping=64, min_damping=1, max_damping=64)
@@ -207,7 +215,7 @@ def test_gtmap_icp_120_frames_batched(ctx, bundled):
                    g["T_out"][f])
 
 
-def test_association_reference_cases(ctx):
+def test_association_reference_cases(ctx, assoc_mode):
     g = load_golden("ref_association.npz")
     i1, i2 = ctx.associate(ctx.to_device(g["app1"]), ctx.to_device(g["app2"]))
     r1, r2 = po.associate(g["app1"], g["app2"])
@@ -233,8 +241,11 @@ def test_association_reference_cases(ctx):
     assert rel_err(np.array(m1["projected_points_1"]), g["m1_proj"]) < 1e-13
 
 
-def test_association_sizes_and_duplicates(ctx):
+def test_association_sizes_and_duplicates(ctx, assoc_mode):
+    """Ragged sizes, repeated descriptors (up to ~40 equal rows per query: beyond what the hash join
+    handles itself, so that mode must hand over to the scan), empty sets."""
     rng = np.random.default_rng(11)
+    before = ctx.association_fallbacks()
     for n1, n2, D in [(1, 1, 10), (3, 5000, 10), (5000, 3, 10), (4097, 4099, 10), (2000, 3000, 3), (300, 300, 1),
                       (70000, 9000, 10)]:
         app2 = rng.integers(-3, 4, (n2, D)).astype(np.float64) if D <= 3 else rng.uniform(-1, 1, (n2, D))
@@ -246,6 +257,25 @@ def test_association_sizes_and_duplicates(ctx):
         assert np.array_equal(i2.cpu().numpy(), r2), (n1, n2, D)
     e1, e2 = ctx.associate(ctx.to_device(np.zeros((0, 10))), ctx.to_device(np.zeros((5, 10))))
     assert e1.numel() == 0 and e2.numel() == 0
+    if assoc_mode == "hash":
+        assert ctx.association_fallbacks() > before      # the (300, 300, 1) case: 7 distinct rows
+
+
+def test_association_signed_zero_and_nan(ctx, assoc_mode):
+    """Float equality, not bit equality: -0.0 matches +0.0; a row holding NaN matches nothing."""
+    rng = np.random.default_rng(12)
+    app2 = rng.uniform(-1, 1, (500, 10))
+    app2[10, 3] = 0.0
+    app2[11, 0] = -0.0
+    app2[12, 5] = np.nan
+    app1 = app2[[10, 11, 12, 13, 10]].copy()
+    app1[0, 3] = -0.0
+    app1[1, 0] = 0.0
+    i1, i2 = ctx.associate(ctx.to_device(app1), ctx.to_device(app2))
+    assert i1.cpu().numpy().tolist() == [0, 1, 3, 4]
+    assert i2.cpu().numpy().tolist() == [10, 11, 13, 10]
+    r1, r2 = po.associate(app1, app2)
+    assert r1.tolist() == [0, 1, 3, 4] and r2.tolist() == [10, 11, 13, 10]
 
 
 @pytest.mark.parametrize("M", [1 << 20, 300_001, 70_000])
