@@ -127,3 +127,46 @@ def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=
                 break
             next_check = rounds + (1 if disable_stop else check_every)
     return stages.finish()
+
+
+def row_bounds(N: int, rank: int, world: int):
+    """Contiguous, near-equal slice [lo, hi) of N query rows for ``rank``."""
+    per = -(-N // world)
+    lo = min(rank * per, N)
+    return lo, min(lo + per, N)
+
+
+def associate_sharded(associate, app1_local, app2, lo, group=None):
+    """Appearance association with the query rows (set 1) sharded and set 2 replicated.
+
+    ``associate(app1_local, app2) -> (idx1, idx2)`` is the single-device association (``Context.associate``;
+    int64 tensors, query-major order, idx1 local to the shard).  Rank r holds the rows
+    [lo, hi) = row_bounds(N1, r, world) of set 1.  The pairs of a shard are already in the reference's
+    order (src/data_association.py:29-30) and the shards are contiguous in rank order, so the global
+    list is the concatenation of the shards' lists: one all-gather of the pair counts and one of the
+    (padded) index lists, no other exchange.  Returns (idx1, idx2) with global set-1 row numbers,
+    identical on every rank; with no process group it is the local result shifted by ``lo``."""
+    import torch
+    import torch.distributed as dist
+    i1, i2 = associate(app1_local, app2)
+    i1 = i1 + int(lo)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return i1, i2
+    world = dist.get_world_size(group)
+    through_host = dist.get_backend(group) != "nccl" and i1.is_cuda
+    dev = i1.device
+    if through_host:
+        i1, i2 = i1.cpu(), i2.cpu()
+    n = torch.tensor([i1.numel()], dtype=torch.int64, device=i1.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    mine = torch.zeros((2, width), dtype=torch.int64, device=i1.device)
+    mine[0, : i1.numel()] = i1
+    mine[1, : i2.numel()] = i2
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    g1 = torch.cat([p[0, :c] for p, c in zip(parts, counts)])
+    g2 = torch.cat([p[1, :c] for p, c in zip(parts, counts)])
+    return g1.to(dev), g2.to(dev)

@@ -77,3 +77,54 @@ def test_two_rank_run_equals_single_process(M, num_iterations, disable_stop):
         assert len(err) == len(h_ref["error"])
         assert rel_err(T, T_ref) < 1e-9
     assert np.array_equal(results[0][1], results[1][1])           # replicas stay bit-identical
+
+
+def _assoc_rank(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharded = importlib.import_module("monocular-visual-odometry_amd").sharded
+    app1, app2 = _assoc_problem()
+    lo, hi = sharded.row_bounds(len(app1), rank, world)
+
+    def associate(a1, a2):      # the CPU restatement stands in for the device association
+        r1, r2 = po.associate(a1, a2)
+        return torch.from_numpy(np.asarray(r1, dtype=np.int64)), torch.from_numpy(np.asarray(r2, dtype=np.int64))
+
+    g1, g2 = sharded.associate_sharded(associate, app1[lo:hi], app2, lo)
+    out.put((rank, g1.numpy(), g2.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _assoc_problem():
+    rng = np.random.default_rng(21)
+    app2 = rng.integers(-2, 3, (400, 3)).astype(np.float64)        # many repeated descriptors
+    app1 = app2[rng.integers(0, 400, 301)].copy()
+    app1[::5] = rng.uniform(-1, 1, (len(app1[::5]), 3))            # some rows without a partner
+    return app1, app2
+
+
+def test_row_bounds_cover_everything_once():
+    for N in (0, 1, 5, 301, 10**6):
+        for world in (1, 2, 3, 8):
+            spans = [pkg.sharded.row_bounds(N, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == N
+            assert all(b == c and a <= b for (a, b), (c, d) in zip(spans, spans[1:]))
+
+
+def test_two_rank_association_equals_single_process():
+    app1, app2 = _assoc_problem()
+    r1, r2 = po.associate(app1, app2)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_assoc_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, g1, g2 in results:
+        assert np.array_equal(g1, r1) and np.array_equal(g2, r2)      # same pairs, same order, on every rank
