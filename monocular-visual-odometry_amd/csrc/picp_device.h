@@ -569,24 +569,15 @@ __device__ inline double numpy_sum10(const double* a) {
     return s;
 }
 
-struct StepRecord {
-    double H[36];
-    double b[6];
-    double dx[6];
-    double error;
-    double n_inliers, n_inside, n_stage1, n_stage2, used_stage2, mean_stage1, done;
-};
+// ---- one iteration's tail: set choice, solve, pose update, schedules, state, history ----------
+// (src/ProjectiveICP.py:300-321, :269-271, :200-238).  The work has two independent serial chains --
+// the pose chain (damped solve -> v2T -> pose product -> inverse) and the schedule chain (threshold,
+// error-slope statistics, counters, damping, stop test), which needs only the error and the inlier
+// count, i.e. the stage records -- plus copies.  A workgroup runs the two chains on lane 0 of two
+// different waves at the same time, a third wave fills the history row's H and b, and after one
+// barrier the lanes write the state block and the history row in parallel.
 
-// One iteration's serial tail, run by a single lane: choose the inlier set
-// (src/ProjectiveICP.py:300-321), damped solve and pose update (:269-271), schedules (:200-228),
-// state update and history row (:231-238).
-// st: the state block (read and written).  s1/s2: the reduced stage records.
-// hist_row: this iteration's history row or nullptr.
-// Returns false when the iteration could not be completed because the stage-2 record holds the
-// mean-filtered set F and F has fewer than min_inliers members: the state's mode flag is then set
-// and nothing else changes; the caller runs the stages again (stage 2 then sums the stage-1 set).
-// Fills the H, b and padding entries of a history row from the stage records.  These do not depend
-// on the serial step, so the lanes that would otherwise idle write them (tid = 0..63 of any wave).
+// Fills the H, b and padding entries of a history row from the stage records (lanes tid = 0..63).
 __device__ __forceinline__ void fill_history_linear(double* hist_row, const double* s1, const double* s2, int tid) {
     const bool have = (s1[S1_N_INSIDE] != 0.0) && (s1[S1_COUNT] != 0.0);
     if (tid < 36) {
@@ -601,97 +592,108 @@ __device__ __forceinline__ void fill_history_linear(double* hist_row, const doub
     }
 }
 
-// linear_by_others: the caller fills H, b and the padding of the history row with fill_history_linear.
-__device__ inline bool solve_and_schedule(double* st, const double* s1, const double* s2, const picp_schedule& sc,
-                                          double* hist_row, bool linear_by_others = false) {
-    const double n_inside = s1[S1_N_INSIDE];
-    const double n1 = s1[S1_COUNT];
-    const bool redo_mode = (st[ST_MODE] != 0.0);
-    if (n_inside != 0.0 && n1 != 0.0 && !redo_mode && s2[S2_N] < (double)sc.min_inliers) { // :307
-        st[ST_MODE] = 1.0;
-        st[ST_N_STAGE2] = s2[S2_N];
-        return false;
-    }
-    StepRecord r;
-#pragma unroll
-    for (int i = 0; i < 36; ++i) r.H[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        r.b[i] = 0.0;
-        r.dx[i] = 0.0;
-    }
-    r.n_inside = n_inside;
-    r.n_stage1 = n1;
-    r.n_stage2 = 0.0;
-    r.used_stage2 = 0.0;
-    r.mean_stage1 = 0.0;
+// Workgroup-shared results of the two chains (LDS).
+struct StepShared {
+    double T1[16];   // pose after the step (:271)
+    double Tinv[16]; // its inverse, the next camera state (:232)
+    double dx[6];
+    // from the schedule chain
+    double error, n_inliers, n_stage2, used_stage2, mean_stage1, done;
+    double thr, lam, mean_slope, sigma_slope, stuck, flicker, slope, stop;
+    int it;        // 1-based number of this iteration (:179)
+    int ring_slot; // slot of the slope ring buffer that receives `slope`, or -1
+    int improved;  // this iteration's error is the smallest so far (first minimum wins, :249)
+};
+
+// Pose chain, one lane: H and b of the chosen set, damped solve, v2T, pose product, inverse.
+__device__ inline void step_pose_chain(const double* st, const double* s1, const double* s2, StepShared* sh) {
     double T1[16];
-    const double lambda = st[ST_LAMBDA];
-    double thr = st[ST_THR];
-    if (n_inside == 0.0) {
+    double dx[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dx[i] = 0.0;
+    if (s1[S1_N_INSIDE] == 0.0) {
         // __one_step returns before the solve when there are no points (:263)
-        r.done = 0.0;
-        r.error = d_inf();
-        r.n_inliers = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) T1[i] = st[ST_W_T_C + i];
     } else {
-        r.done = 1.0;
-        if (n1 == 0.0) { // :300
-            r.n_inliers = 0.0;
-            r.error = d_inf();
+        double H[36], b[6];
+        if (s1[S1_COUNT] == 0.0) { // :300: H = 0, b = 0
+#pragma unroll
+            for (int i = 0; i < 36; ++i) H[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) b[i] = 0.0;
         } else {
-            r.mean_stage1 = s1[S1_SUM_CHI] / n1;
-            r.used_stage2 = redo_mode ? 0.0 : 1.0;
-            // in redo mode the number of mean-filter survivors was kept in the state block
-            r.n_stage2 = redo_mode ? st[ST_N_STAGE2] : s2[S2_N];
             int k = 0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
 #pragma unroll
                 for (int j = i; j < 6; ++j) {
                     const double h = s2[S2_H + k];
-                    r.H[i * 6 + j] = h;
-                    r.H[j * 6 + i] = h;
+                    H[i * 6 + j] = h;
+                    H[j * 6 + i] = h;
                     ++k;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) r.b[i] = s2[S2_B + i];
-            r.n_inliers = s2[S2_N];
-            r.error = (r.n_inliers > 0.0) ? s2[S2_CHI] / r.n_inliers : d_inf(); // :319-321
+            for (int i = 0; i < 6; ++i) b[i] = s2[S2_B + i];
         }
-        damped_solve6(r.H, r.b, lambda, r.dx); // :269-270
+        damped_solve6(H, b, st[ST_LAMBDA], dx); // :269-270
         double dT[16];
-        v2T_device(r.dx, dT);
+        v2T_device(dx, dT);
         matmul4(st + ST_W_T_C, dT, T1); // :271
     }
-    st[ST_MODE] = 0.0;
+    double Tinv[16];
+    invert_pose(T1, Tinv);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sh->T1[i] = T1[i];
+        sh->Tinv[i] = Tinv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sh->dx[i] = dx[i];
+}
 
+// Schedule chain, one lane: error and inlier count of the chosen set, then :200-228.
+__device__ inline void step_schedule_chain(const double* st, const double* s1, const double* s2,
+                                           const picp_schedule& sc, StepShared* sh) {
+    const double n_inside = s1[S1_N_INSIDE];
+    const double n1 = s1[S1_COUNT];
+    const bool redo_mode = (st[ST_MODE] != 0.0);
+    double error = d_inf(), n_inliers = 0.0, n_stage2 = 0.0, used_stage2 = 0.0, mean_stage1 = 0.0;
+    const bool done = (n_inside != 0.0); // :263 vs :273
+    if (done && n1 != 0.0) {
+        mean_stage1 = s1[S1_SUM_CHI] / n1;
+        used_stage2 = redo_mode ? 0.0 : 1.0;
+        // in redo mode the number of mean-filter survivors was kept in the state block
+        n_stage2 = redo_mode ? st[ST_N_STAGE2] : s2[S2_N];
+        n_inliers = s2[S2_N];
+        error = (n_inliers > 0.0) ? s2[S2_CHI] / n_inliers : d_inf(); // :319-321
+    }
     // kernel threshold schedule (:200-205)
-    if (r.n_inliers == n_inside) {
+    double thr = st[ST_THR];
+    if (n_inliers == n_inside) {
         thr = sc.min_kernel_threshold;
-    } else if (r.n_inliers < (double)sc.min_inliers) {
+    } else if (n_inliers < (double)sc.min_inliers) {
         if (thr + 10.0 <= sc.max_kernel_threshold) thr += 10.0;
     } else {
         if (thr - 10.0 >= sc.min_kernel_threshold) thr -= 10.0;
     }
-
     // error slope statistics (:208-213); `it` is 1-based as in the reference (:179)
     const int it = (int)st[ST_IT] + 1;
     const double error_prev = st[ST_ERR_PREV];
     double mean_slope = st[ST_MEAN_SLOPE], sigma_slope = st[ST_SIGMA_SLOPE];
+    int ring_slot = -1;
+    double slope = 0.0;
     if (it > 1) {
         const double inf = d_inf();
-        const double slope = (r.error == inf || error_prev == inf) ? 1e3 : fabs(error_prev - r.error);
+        slope = (error == inf || error_prev == inf) ? 1e3 : fabs(error_prev - error);
         double ring[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) ring[i] = st[ST_RING + i];
-        const int slot = it % 10;
+        ring_slot = it % 10;
 #pragma unroll
         for (int i = 0; i < 10; ++i)
-            if (i == slot) ring[i] = slope;
-        st[ST_RING + slot] = slope;
+            if (i == ring_slot) ring[i] = slope;
         mean_slope = numpy_sum10(ring) / 10.0; // np.mean
         double dev[10];
 #pragma unroll
@@ -701,68 +703,99 @@ __device__ inline bool solve_and_schedule(double* st, const double* s1, const do
         }
         sigma_slope = sqrt(numpy_sum10(dev) / 10.0); // np.std (population)
     }
-    const bool done = (r.done != 0.0);
     double stuck = st[ST_STUCK], flicker = st[ST_FLICKER];
     stuck = (done && mean_slope < 1e-2 && sigma_slope < 1e-2) ? stuck + 1.0 : 0.0; // :216-217
     flicker = (done && mean_slope > 1.0 && sigma_slope > 1.0) ? flicker + 1.0 : 0.0; // :220-221
-
     // damping schedule (:224-225), limit = 10 (:164)
-    double lam = lambda;
+    double lam = st[ST_LAMBDA];
     if ((lam / 2.0) >= sc.min_damping && (stuck > 10.0 || (stuck == 0.0 && flicker == 0.0))) lam /= 2.0;
     if ((lam * 2.0) <= sc.max_damping && flicker > 10.0) lam *= 2.0;
-
-    bool stop = done && (r.error < 0.01 || stuck > 100.0) && (sc.disable_stop == 0); // :228
-    if (it >= sc.num_iterations) stop = true;                                        // :178
-
-    // state update (:231-238)
-    double Tinv[16];
-    invert_pose(T1, Tinv);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        st[ST_W_T_C + i] = T1[i];
-        st[ST_C_T_W + i] = Tinv[i];
-    }
-    st[ST_THR] = thr;
-    st[ST_LAMBDA] = lam;
-    st[ST_ERR_PREV] = r.error;
-    st[ST_MEAN_SLOPE] = mean_slope;
-    st[ST_SIGMA_SLOPE] = sigma_slope;
-    st[ST_STUCK] = stuck;
-    st[ST_FLICKER] = flicker;
-    st[ST_IT] = (double)it;
-    st[ST_STOP] = stop ? 1.0 : 0.0;
+    bool stop = done && (error < 0.01 || stuck > 100.0) && (sc.disable_stop == 0); // :228
+    if (it >= sc.num_iterations) stop = true;                                      // :178
+    sh->error = error;
+    sh->n_inliers = n_inliers;
+    sh->n_stage2 = n_stage2;
+    sh->used_stage2 = used_stage2;
+    sh->mean_stage1 = mean_stage1;
+    sh->done = done ? 1.0 : 0.0;
+    sh->thr = thr;
+    sh->lam = lam;
+    sh->mean_slope = mean_slope;
+    sh->sigma_slope = sigma_slope;
+    sh->stuck = stuck;
+    sh->flicker = flicker;
+    sh->slope = slope;
+    sh->stop = stop ? 1.0 : 0.0;
+    sh->it = it;
+    sh->ring_slot = ring_slot;
     // np.argmin returns the first minimum; NaN would win in numpy, which cannot arise here
     // because a NaN chi never passes chi <= threshold.
-    if (it == 1 || r.error < st[ST_BEST_ERR]) {
-        st[ST_BEST_ERR] = r.error;
-        st[ST_BEST_IT] = (double)(it - 1);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) st[ST_BEST_T + i] = T1[i];
-    }
+    sh->improved = (it == 1 || error < st[ST_BEST_ERR]) ? 1 : 0;
+}
 
-    if (hist_row != nullptr) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) hist_row[PICP_H_T + i] = T1[i];
-        hist_row[PICP_H_ERROR] = r.error;
-        hist_row[PICP_H_NUM_INLIERS] = r.n_inliers;
-        hist_row[PICP_H_KERNEL_THR] = thr;
-        hist_row[PICP_H_DAMPING] = lam;
-        hist_row[PICP_H_N_INSIDE] = r.n_inside;
-        hist_row[PICP_H_DONE] = r.done;
-        hist_row[PICP_H_N_STAGE1] = r.n_stage1;
-        hist_row[PICP_H_N_STAGE2] = r.n_stage2;
-        hist_row[PICP_H_USED_STAGE2] = r.used_stage2;
-        hist_row[PICP_H_MEAN_STAGE1] = r.mean_stage1;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) hist_row[PICP_H_DX + i] = r.dx[i];
-        if (!linear_by_others) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) hist_row[PICP_H_B + i] = r.b[i];
-#pragma unroll
-            for (int i = 0; i < 36; ++i) hist_row[PICP_H_H + i] = r.H[i];
-            for (int i = PICP_H_H + 36; i < PICP_HIST_STRIDE; ++i) hist_row[i] = 0.0;
+// The whole tail, called by every thread of a workgroup of at least 192 threads.
+// st: the state block (LDS or global; read, then written).  s1/s2: the reduced stage records.
+// hist_row: this iteration's history row or nullptr.  sh: LDS scratch.
+// Returns false (to every thread) when the iteration could not be completed because the stage-2
+// record holds the mean-filtered set F and F has fewer than min_inliers members (:307): the state's
+// mode flag is then set and nothing else changes; the caller runs the stages again (stage 2 then
+// sums the stage-1 set).  Ends with a workgroup barrier.
+__device__ __forceinline__ bool solve_step(double* st, const double* s1, const double* s2, const picp_schedule& sc,
+                                           double* hist_row, StepShared* sh) {
+    const int tid = threadIdx.x;
+    const bool redo_mode = (st[ST_MODE] != 0.0);
+    const double n_set = s2[S2_N];
+    if (s1[S1_N_INSIDE] != 0.0 && s1[S1_COUNT] != 0.0 && !redo_mode && n_set < (double)sc.min_inliers) { // :307
+        __syncthreads(); // every thread has read the mode flag
+        if (tid == 0) {
+            st[ST_MODE] = 1.0;
+            st[ST_N_STAGE2] = n_set;
         }
+        __syncthreads();
+        return false;
     }
+    if (tid == 0) step_pose_chain(st, s1, s2, sh);
+    if (tid == 64) step_schedule_chain(st, s1, s2, sc, sh);
+    if (hist_row != nullptr && tid >= 128 && tid < 192) fill_history_linear(hist_row, s1, s2, tid - 128);
+    __syncthreads();
+    // state update (:231-238) and history row, one entry per lane
+    if (tid < 16) {
+        const double t = sh->T1[tid];
+        st[ST_W_T_C + tid] = t;
+        st[ST_C_T_W + tid] = sh->Tinv[tid];
+        if (sh->improved) st[ST_BEST_T + tid] = t;
+        if (hist_row != nullptr) hist_row[PICP_H_T + tid] = t;
+    } else if (tid < 22) {
+        if (hist_row != nullptr) hist_row[PICP_H_DX + (tid - 16)] = sh->dx[tid - 16];
+    } else if (tid == 22) {
+        st[ST_THR] = sh->thr;
+        st[ST_LAMBDA] = sh->lam;
+        st[ST_ERR_PREV] = sh->error;
+        st[ST_MEAN_SLOPE] = sh->mean_slope;
+        st[ST_SIGMA_SLOPE] = sh->sigma_slope;
+        st[ST_STUCK] = sh->stuck;
+        st[ST_FLICKER] = sh->flicker;
+        st[ST_IT] = (double)sh->it;
+        st[ST_STOP] = sh->stop;
+        st[ST_MODE] = 0.0;
+        if (sh->ring_slot >= 0) st[ST_RING + sh->ring_slot] = sh->slope;
+        if (sh->improved) {
+            st[ST_BEST_ERR] = sh->error;
+            st[ST_BEST_IT] = (double)(sh->it - 1);
+        }
+    } else if (tid == 23 && hist_row != nullptr) {
+        hist_row[PICP_H_ERROR] = sh->error;
+        hist_row[PICP_H_NUM_INLIERS] = sh->n_inliers;
+        hist_row[PICP_H_KERNEL_THR] = sh->thr;
+        hist_row[PICP_H_DAMPING] = sh->lam;
+        hist_row[PICP_H_N_INSIDE] = s1[S1_N_INSIDE];
+        hist_row[PICP_H_DONE] = sh->done;
+        hist_row[PICP_H_N_STAGE1] = s1[S1_COUNT];
+        hist_row[PICP_H_N_STAGE2] = sh->n_stage2;
+        hist_row[PICP_H_USED_STAGE2] = sh->used_stage2;
+        hist_row[PICP_H_MEAN_STAGE1] = sh->mean_stage1;
+    }
+    __syncthreads();
     return true;
 }
 

@@ -193,8 +193,8 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
     __shared__ double lds[NT_SOLVE];
     __shared__ double s1[PICP_S1_DOUBLES];
     __shared__ double s2[PICP_S2_DOUBLES];
-    // The serial step runs on one lane against copies of the state block and the history row in
-    // LDS; both are moved to and from global memory by the whole workgroup.  All global loads of
+    // The tail (solve_step) runs against copies of the state block and the history row in LDS;
+    // both are moved to and from global memory by the whole workgroup.  All global loads of
     // the prologue -- both sets of partial records and the state block -- are issued before the
     // first wait, so the kernel pays one memory round trip, not three.
     __shared__ double st[PICP_STATE_DOUBLES];
@@ -214,12 +214,10 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
         if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = t2;
         __syncthreads();
     }
-    __shared__ int advanced;
+    __shared__ StepShared sh;
     const int it = (int)st[ST_IT];
     const bool record = (hist != nullptr && it < hist_rows);
-    if (threadIdx.x == 0) advanced = solve_and_schedule(st, s1, s2, sc, record ? row : nullptr, true) ? 1 : 0;
-    if (record && threadIdx.x >= 64 && threadIdx.x < 128) fill_history_linear(row, s1, s2, threadIdx.x - 64);
-    __syncthreads();
+    const bool advanced = solve_step(st, s1, s2, sc, record ? row : nullptr, &sh);
     if (threadIdx.x < PICP_STATE_DOUBLES) state[threadIdx.x] = st[threadIdx.x];
     if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
         hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
@@ -240,6 +238,7 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
     __shared__ double lds[(NT / 64) * 64];
     __shared__ double s1[PICP_S1_DOUBLES];
     __shared__ double s2[PICP_S2_DOUBLES];
+    __shared__ StepShared sh;
     const int prob = blockIdx.x;
     const int64_t beg = offsets[prob];
     const int cnt = (int)(offsets[prob + 1] - beg);
@@ -306,12 +305,11 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
                 if (threadIdx.x < S2_USED) s2[threadIdx.x] = tot;
                 __syncthreads();
             }
-            if (threadIdx.x == 0) {
+            {
                 const int it = (int)st[ST_IT];
                 double* row = (myhist != nullptr && it < hist_rows) ? myhist + (size_t)it * PICP_HIST_STRIDE : nullptr;
-                solve_and_schedule(st, s1, s2, sc, row);
+                (void)solve_step(st, s1, s2, sc, row, &sh);
             }
-            __syncthreads();
             if (st[ST_MODE] == 0.0) break;
         }
     }

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     __shared__ double s2[PICP_S2_DOUBLES];
     __shared__ double row[PICP_HIST_STRIDE];
     __shared__ int flag;
-    __shared__ int advanced;
+    __shared__ StepShared sh;
     // Dynamic LDS, thread-private columns (conflict-free): the measurements u, v as [R][2][NTR]
     // (they are only read, once or twice per iteration, so they need not occupy registers) and the
     // stage-1 results kept for stage 2 (chi, 1/z) as [R][2][NTR].
@@ -282,9 +282,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         }
 
         const bool record = (blockIdx.x == 0 && hist != nullptr && it < hist_rows);
-        if (threadIdx.x == 0) advanced = solve_and_schedule(st, s1, s2, sc, record ? row : nullptr, true) ? 1 : 0;
-        if (record && threadIdx.x >= 64 && threadIdx.x < 128) fill_history_linear(row, s1, s2, threadIdx.x - 64);
-        __syncthreads();
+        const bool advanced = solve_step(st, s1, s2, sc, record ? row : nullptr, &sh);
         if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
             hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
     }
