@@ -219,12 +219,6 @@ struct SetSums {
 };
 
 // ---- wavefront (64 lanes) and workgroup sums -------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 template <int CTRL>
@@ -253,6 +247,21 @@ __device__ __forceinline__ double halve_dpp(double a, double b, bool up) {
     const double keep = up ? b : a;
     const double send = up ? a : b;
     return keep + dpp_move<CTRL>(send);
+}
+
+// Sum of one value over the 64 lanes of a wave, returned in every lane: a butterfly over the lane
+// bits with the data-parallel-primitive moves (row_mirror, row_half_mirror, two quad permutes: the
+// partner sets of successive steps are disjoint, so four steps give the sum of each row of 16)
+// and the two lane swaps for bits 4 and 5.  No LDS traffic, unlike a ds_bpermute shuffle: about
+// 20 instructions and 6 short dependent steps.  Fixed order, reproducible.
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_move<0x140>(v); // row_mirror:      l <-> 15 - l
+    v += dpp_move<0x141>(v); // row_half_mirror: l <-> 7 - l within each 8
+    v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = halve_bit4(v, v);    // rows 0<->1, 2<->3
+    v = halve_bit5(v, v);    // lanes 0..31 <-> 32..63
+    return v;
 }
 
 // Column sums of a 64 x N matrix held one row per lane (N = 32 or 64): v[j] of lane l is element
