@@ -58,7 +58,8 @@ int hip_fail(hipError_t e, const char* what);
 int64_t resident_capacity(const picp_ctx* ctx);
 int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
-                     const picp_schedule* sched, double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1);
+                     const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
+                     hipEvent_t e1);
 
 struct DeviceGuard {
     int prev = -1;

@@ -357,6 +357,20 @@ static int check_corr(const double* u, const double* v, const double* x, const d
     return PICP_OK;
 }
 
+// The best-iteration rule on a host copy of the state block (src/ProjectiveICP.py:249-257):
+// invalid when the smallest error is > 5 (NaN-free by construction); then the start pose is returned.
+static void result_from_state(const double* h, const double* w_T_c0_host, picp_result* result) {
+    const int n_it = (int)h[ST_IT];
+    const bool valid = n_it > 0 && !(h[ST_BEST_ERR] > 5.0);
+    for (int i = 0; i < 16; ++i)
+        result->T[i] = valid ? h[ST_BEST_T + i] : (w_T_c0_host ? w_T_c0_host[i] : h[ST_START_T + i]);
+    result->valid = valid ? 1 : 0;
+    result->num_iterations = n_it;
+    result->best_index = (int)h[ST_BEST_IT];
+    result->reserved = 0;
+    result->best_error = h[ST_BEST_ERR];
+}
+
 static int check_pose(const double* T) {
     PICP_REQUIRE(T != nullptr, "null pose");
     PICP_REQUIRE(T[12] == 0.0 && T[13] == 0.0 && T[14] == 0.0 && T[15] == 1.0,
@@ -483,7 +497,7 @@ int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const doub
     double sum = 0.0, best = 1e30;
     int rc = PICP_OK;
     for (int r = 0; r < reps && rc == PICP_OK; ++r) {
-        rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, nullptr, 0, e0, e1);
+        rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, nullptr, 0, nullptr, e0, e1);
         if (rc != PICP_OK) break;
         hipError_t e = hipEventSynchronize(e1);
         float ms = 0.f;
@@ -536,15 +550,7 @@ int picp_finish(picp_ctx* ctx, const double* state, const double* hist, int32_t 
     double* h = ctx->pinned;
     PICP_HIP_CHECK(hipMemcpyAsync(h, state, PICP_STATE_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const int n_it = (int)h[ST_IT];
-    // src/ProjectiveICP.py:249-257: invalid when the smallest error is > 5 (NaN-free by construction)
-    const bool valid = n_it > 0 && !(h[ST_BEST_ERR] > 5.0);
-    for (int i = 0; i < 16; ++i) result->T[i] = valid ? h[ST_BEST_T + i] : (w_T_c0_host ? w_T_c0_host[i] : h[ST_START_T + i]);
-    result->valid = valid ? 1 : 0;
-    result->num_iterations = n_it;
-    result->best_index = (int)h[ST_BEST_IT];
-    result->reserved = 0;
-    result->best_error = h[ST_BEST_ERR];
+    result_from_state(h, w_T_c0_host, result);
     return PICP_OK;
 }
 
@@ -561,10 +567,13 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
     // Inputs that fit the register files run the whole loop in one launch (picp_resident.hip).
     if (M > 0 && M <= resident_capacity(ctx) && sched->num_iterations > 0) {
         if (int rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
-                                      nullptr, nullptr))
+                                      ctx->pinned, nullptr, nullptr))
             return rc;
-        if (int rc = picp_finish(ctx, state, hist, hist_rows, w_T_c0_host, result)) return rc; // synchronises
-        if (ctx->pinned[ST_STOP] != 0.0) return PICP_OK; // picp_finish left the state block in ctx->pinned
+        PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // the kernel left the final state in ctx->pinned
+        if (ctx->pinned[ST_STOP] != 0.0) {
+            result_from_state(ctx->pinned, w_T_c0_host, result);
+            return PICP_OK;
+        }
         // the launch was abandoned at a grid-wide wait (device shared with other work): start over
         ctx->resident_aborts += 1;
     }

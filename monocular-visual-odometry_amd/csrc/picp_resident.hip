@@ -190,7 +190,8 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
                                                           const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, int64_t M,
                                                           double* __restrict__ state, CameraK cam, picp_schedule sc,
-                                                          GridExchange gx, double* __restrict__ hist, int hist_rows) {
+                                                          GridExchange gx, double* __restrict__ hist, int hist_rows,
+                                                          double* __restrict__ host_state) {
     __shared__ double st[PICP_STATE_DOUBLES];
     __shared__ double lds[NTR];
     __shared__ double s1[PICP_S1_DOUBLES];
@@ -286,7 +287,11 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
             hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
     }
-    if (blockIdx.x == 0 && threadIdx.x < PICP_STATE_DOUBLES) state[threadIdx.x] = st[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < PICP_STATE_DOUBLES) {
+        state[threadIdx.x] = st[threadIdx.x];
+        // a second copy straight into host-visible memory spares the caller a device-to-host copy
+        if (host_state != nullptr) host_state[threadIdx.x] = st[threadIdx.x];
+    }
 }
 
 static CameraK camera_of(const picp_camera* cam) {
@@ -307,7 +312,8 @@ int64_t resident_capacity(const picp_ctx* ctx) {
 template <int R>
 static void launch_resident(picp_ctx* ctx, int grid, const double* u, const double* v, const double* x, const double* y,
                             const double* z, int64_t M, double* state, const picp_camera* cam,
-                            const picp_schedule* sched, double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1) {
+                            const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
+                            hipEvent_t e1) {
     const CameraK c = camera_of(cam);
     GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
     auto kern = is_pinhole(cam->K) ? icp_resident_kernel<R, true> : icp_resident_kernel<R, false>;
@@ -323,18 +329,20 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
     }
     if (e0 != nullptr)
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, c, *sched,
-                              gx, hist, hist_rows);
+                              gx, hist, hist_rows, host_state);
     else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, u, v, x, y, z, M, state, c, *sched, gx,
-                           hist, hist_rows);
+                           hist, hist_rows, host_state);
 }
 
 // Enqueues loop entry (state block from w_T_c0_host) and the loop.  Precondition:
 // 0 < M <= resident_capacity(ctx).  A launch that gave up at a grid-wide wait leaves the state's
-// stop flag clear (the final state is only written by a loop that ran to its end).
+// stop flag clear (the final state is only written by a loop that ran to its end).  host_state:
+// optional host-visible (pinned) block that also receives the final state, cleared here first.
 int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
-                     const picp_schedule* sched, double* hist, int hist_rows, hipEvent_t e0, hipEvent_t e1) {
+                     const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
+                     hipEvent_t e1) {
     PICP_REQUIRE(M > 0 && M <= resident_capacity(ctx), "resident loop: %lld correspondences exceed the capacity",
                  (long long)M);
     // fewest correspondences per thread that still fit one workgroup per CU, then no more
@@ -346,15 +354,16 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     PICP_REQUIRE(grid >= 1 && grid <= resident_grid(ctx), "resident loop: grid %d does not fit %d CUs", grid,
                  resident_grid(ctx));
     const int n = SLOTS * grid * RW;
+    if (host_state != nullptr) host_state[ST_STOP] = 0.0;
     StartPose pose;
     memcpy(pose.m, w_T_c0_host, sizeof(pose.m));
     hipLaunchKernelGGL(resident_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->rslots, n, state,
                        pose, sched->kernel_threshold, sched->damping, sched->num_iterations);
     switch (R) {
-    case 1: launch_resident<1>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
-    case 2: launch_resident<2>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
-    case 4: launch_resident<4>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
-    default: launch_resident<8>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, e0, e1); break;
+    case 1: launch_resident<1>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
+    case 2: launch_resident<2>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
+    case 4: launch_resident<4>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
+    default: launch_resident<8>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
     }
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
