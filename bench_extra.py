@@ -39,11 +39,11 @@ def main():
     corr = ctx.soa(uv, pw)
     offsets = ctx.to_device(np.arange(B + 1, dtype=np.int64) * N, np.int64)
     poses0 = ctx.to_device(np.tile(np.eye(4).reshape(1, 16), (B, 1)))
-    ctx.run_batched(corr, offsets, poses0, cam, sched)
+    ctx.run_batched(corr, offsets, poses0, cam, sched, max_count=N)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.reps):
-        results, _ = ctx.run_batched(corr, offsets, poses0, cam, sched)
+        results, _ = ctx.run_batched(corr, offsets, poses0, cam, sched, max_count=N)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.reps
     print(json.dumps({"config": f"batched ICP, {B} problems x {N} correspondences, 20 LM iterations, one workgroup each",

@@ -139,11 +139,15 @@ int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const doub
  * inside the kernel.  Problem p owns correspondences [offsets[p], offsets[p+1]).
  * offsets: device int64[B+1]; poses0: device [B][16]; results: device picp_result[B];
  * hist: device [B][hist_rows][PICP_HIST_STRIDE] or NULL (then only results are produced).
+ * max_count: an upper bound on the size of every problem, or 0 if the caller has none (offsets is
+ * device memory, so the library cannot look).  With a bound of at most 4 096 the problems are held
+ * in registers and LDS for the whole loop; otherwise they are re-read from memory every iteration.
+ * A problem that exceeds a non-zero bound is not run: its result has num_iterations = -1.
  * Does not synchronise. */
 int picp_run_batched(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, const int64_t* offsets, int32_t B, const double* poses0,
                      const picp_camera* cam, const picp_schedule* sched, picp_result* results, double* hist,
-                     int32_t hist_rows);
+                     int32_t hist_rows, int64_t max_count);
 
 /* ---- the loop's stages, for callers that interleave their own exchange (sharded runs) ------
  * picp_state_init   = loop entry (:157-171): pose, inverse pose, thresholds, counters.

@@ -18,10 +18,6 @@ from .data_association import data_association_on_appearance, match_indices
 from .two_view import essential_from_matches, recover_pose, triangulate_points
 from .geometry_utils import Rt2T
 
-# Below this many matched pairs the whole loop runs inside one workgroup (one launch for all
-# iterations); above it every iteration is two device-wide scans plus a solve launch.
-SINGLE_WORKGROUP_MAX_PAIRS = 8192
-
 
 class ProjectiveICP:
     def __init__(self, camera,
@@ -76,18 +72,6 @@ class ProjectiveICP:
         """All iterations on the device.  Returns (result struct, history ndarray [n_it, HIST_STRIDE])."""
         ctx = self.__ctx
         cam = self.__camera_struct()
-        M = int(corr[0].numel())
-        if M <= SINGLE_WORKGROUP_MAX_PAIRS:
-            offsets = ctx.to_device(np.array([0, M], dtype=np.int64), np.int64)
-            pose0 = ctx.to_device(np.asarray(w_T_c0, dtype=np.float64).reshape(1, 16))
-            results, hist = ctx.run_batched(corr, offsets, pose0, cam, sched, want_history=True)
-            r = ctx.decode_results(results.cpu().numpy())
-            res = _lib.ResultStruct()
-            for i in range(16):
-                res.T[i] = float(r["T"][0].reshape(16)[i])
-            res.valid, res.num_iterations = int(r["valid"][0]), int(r["num_iterations"][0])
-            res.best_index, res.best_error = int(r["best_index"][0]), float(r["best_error"][0])
-            return res, hist[0, :res.num_iterations].cpu().numpy()
         return ctx.run(corr, w_T_c0, cam, sched, want_history=True)
 
     # ---- the reference's public methods ------------------------------------------------------------

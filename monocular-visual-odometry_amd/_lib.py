@@ -72,7 +72,7 @@ _SIGNATURES = {
                                    C.POINTER(ScheduleStruct), _P, C.c_int32, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
     "picp_run_batched": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(CameraStruct),
-                                   C.POINTER(ScheduleStruct), _P, _P, C.c_int32]),
+                                   C.POINTER(ScheduleStruct), _P, _P, C.c_int32, C.c_int64]),
     "picp_state_init": (C.c_int, [_P, _P, _P, C.POINTER(ScheduleStruct)]),
     "picp_stage1": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct)]),
     "picp_stage1_reduce": (C.c_int, [_P, _P]),
@@ -253,16 +253,21 @@ class Context:
         h = hist[: res.num_iterations].cpu().numpy() if want_history else None
         return res, h
 
-    def run_batched(self, corr, offsets, poses0, cam: CameraStruct, sched: ScheduleStruct, want_history=False):
+    def run_batched(self, corr, offsets, poses0, cam: CameraStruct, sched: ScheduleStruct, want_history=False,
+                    max_count=None):
         """picp_run_batched.  offsets: int64 device tensor [B+1]; poses0: device [B,16].
+        max_count: upper bound on the problem sizes (None: read back from ``offsets``, one small
+        synchronising copy); problems of up to 4 096 correspondences then stay on chip for the whole loop.
         Returns (results tensor [B, RESULT_DOUBLES] viewed as float64, history tensor or None); does not sync."""
         B = int(offsets.numel()) - 1
         results = self.empty((B, RESULT_DOUBLES))
         rows = max(int(sched.num_iterations), 1)
         hist = self.zeros((B, rows, HIST_STRIDE)) if want_history else None
+        if max_count is None:
+            max_count = int((offsets[1:] - offsets[:-1]).max().item()) if B > 0 else 0
         check(self.lib.picp_run_batched(self.handle, *[self.ptr(c) for c in corr], self.ptr(offsets), B,
                                         self.ptr(poses0), C.byref(cam), C.byref(sched), self.ptr(results),
-                                        self.ptr(hist), rows if want_history else 0), "picp_run_batched")
+                                        self.ptr(hist), rows if want_history else 0, int(max_count)), "picp_run_batched")
         return results, hist
 
     @staticmethod

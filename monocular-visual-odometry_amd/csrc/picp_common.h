@@ -73,6 +73,12 @@ struct DeviceGuard {
     }
 };
 
+int64_t batched_resident_capacity();
+int enqueue_batched_resident(picp_ctx* ctx, int B, int64_t max_count, const double* u, const double* v, const double* x,
+                             const double* y, const double* z, const int64_t* offsets, const double* poses0,
+                             const picp_camera* cam, const picp_schedule* sched, picp_result* results, double* hist,
+                             int hist_rows);
+
 } // namespace picp
 
 #define PICP_HIP_CHECK(expr)                                           \

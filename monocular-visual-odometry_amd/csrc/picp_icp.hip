@@ -610,13 +610,17 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
 int picp_run_batched(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, const int64_t* offsets, int32_t B, const double* poses0,
                      const picp_camera* cam, const picp_schedule* sched, picp_result* results, double* hist,
-                     int32_t hist_rows) {
+                     int32_t hist_rows, int64_t max_count) {
     PICP_REQUIRE(ctx && offsets && poses0 && cam && sched && results, "picp_run_batched: null argument");
-    PICP_REQUIRE(B >= 0, "picp_run_batched: negative batch");
+    PICP_REQUIRE(B >= 0 && max_count >= 0, "picp_run_batched: negative batch or max_count");
     PICP_REQUIRE(hist == nullptr || hist_rows >= sched->num_iterations,
                  "picp_run_batched: history has %d rows, num_iterations is %d", hist_rows, sched->num_iterations);
     if (B == 0) return PICP_OK;
     DeviceGuard g(ctx->device);
+    // With a bound on the problem size that fits, the problems are held on chip (picp_resident.hip).
+    if (max_count > 0 && max_count <= batched_resident_capacity() && ctx->resident_limit > 0)
+        return enqueue_batched_resident(ctx, B, max_count, u, v, x, y, z, offsets, poses0, cam, sched, results, hist,
+                                        (int)hist_rows);
     const CameraK c = to_device_camera(cam);
     auto kern = is_pinhole(cam->K) ? icp_batched_kernel<0, true> : icp_batched_kernel<0, false>;
     hipLaunchKernelGGL(kern, dim3(B), dim3(NT), 0, ctx->stream, u, v, x, y, z, offsets, poses0, c, *sched, results,

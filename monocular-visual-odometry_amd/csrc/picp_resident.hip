@@ -294,6 +294,127 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     }
 }
 
+// ---- one problem per workgroup, correspondences held on chip ------------------------------------
+// The same loop body for a batch of independent problems (problem p = correspondences
+// [offsets[p], offsets[p+1])): a 256-thread workgroup per problem, R correspondences per thread,
+// no exchange between workgroups.  At most 256 registers per lane, so two workgroups share a CU
+// and one problem's single-lane solve step overlaps the other's stages.  A problem larger than
+// R * 256 correspondences is not run (its result says so: num_iterations = -1); the host picks R
+// from the caller's bound on the problem size.
+constexpr int NTB = 256;
+
+template <int R, bool PINHOLE>
+__global__ __launch_bounds__(NTB, 2) void icp_batched_resident_kernel(
+    const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ x, const double* __restrict__ y,
+    const double* __restrict__ z, const int64_t* __restrict__ offsets, const double* __restrict__ poses0, CameraK cam,
+    picp_schedule sc, picp_result* __restrict__ results, double* __restrict__ hist, int hist_rows) {
+    __shared__ double st[PICP_STATE_DOUBLES];
+    __shared__ double lds[NTB];
+    __shared__ double s1[PICP_S1_DOUBLES];
+    __shared__ double s2[PICP_S2_DOUBLES];
+    __shared__ StepShared sh;
+    extern __shared__ double dyn[]; // u, v as [R][2][NTB], then chi, 1/z of stage 1 as [R][2][NTB]
+    double* muv = dyn;
+    double* kept = dyn + R * 2 * NTB;
+
+    const int prob = blockIdx.x;
+    const int64_t beg = offsets[prob];
+    const int64_t cnt = offsets[prob + 1] - beg;
+    if (cnt > (int64_t)R * NTB) {
+        if (threadIdx.x == 0) {
+            picp_result r;
+            for (int i = 0; i < 16; ++i) r.T[i] = poses0[(size_t)prob * 16 + i];
+            r.valid = 0;
+            r.num_iterations = -1;
+            r.best_index = 0;
+            r.reserved = 0;
+            r.best_error = d_inf();
+            results[prob] = r;
+        }
+        return;
+    }
+    if (threadIdx.x == 0) init_state(st, poses0 + (size_t)prob * 16, sc.kernel_threshold, sc.damping, sc.num_iterations);
+    double rx[R], ry[R], rz[R];
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = (int64_t)r * NTB + threadIdx.x;
+        const bool ok = i < cnt;
+        const int64_t j = beg + (ok ? i : 0);
+        const bool any = cnt > 0;
+        muv[(r * 2 + 0) * NTB + threadIdx.x] = any ? u[j] : 0.0;
+        muv[(r * 2 + 1) * NTB + threadIdx.x] = any ? v[j] : 0.0;
+        rx[r] = any ? x[j] : 0.0;
+        ry[r] = any ? y[j] : 0.0;
+        rz[r] = any ? z[j] : 0.0;
+        mine += ok ? 1 : 0;
+    }
+    __syncthreads();
+    double* myhist = (hist != nullptr) ? hist + (size_t)prob * hist_rows * PICP_HIST_STRIDE : nullptr;
+
+    while (st[ST_STOP] == 0.0) {
+        double T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = uniform(st[ST_C_T_W + i]);
+        const double thr = uniform(st[ST_THR]);
+        const bool all = (st[ST_MODE] != 0.0);
+        const int it = (int)st[ST_IT];
+
+        Stage1Sums a{0.0, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r < mine) {
+                double keep[2];
+                stage1_keep<PINHOLE>(T, cam, thr, muv[(r * 2 + 0) * NTB + threadIdx.x],
+                                     muv[(r * 2 + 1) * NTB + threadIdx.x], rx[r], ry[r], rz[r], a, keep);
+                kept[(r * 2 + 0) * NTB + threadIdx.x] = keep[0];
+                kept[(r * 2 + 1) * NTB + threadIdx.x] = keep[1];
+            }
+        {
+            const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
+            const double tot = block_sum<3, NTB>(vals, lds);
+            if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < 3) ? tot : 0.0;
+            __syncthreads();
+        }
+        const double n1 = s1[S1_COUNT];
+        if (n1 != 0.0) {
+            const double mean = uniform(s1[S1_SUM_CHI] / n1); // np.mean, src/ProjectiveICP.py:301
+            Stage2Sums s;
+            s.clear();
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r < mine) {
+                    const double chi = kept[(r * 2 + 0) * NTB + threadIdx.x];
+                    if ((chi <= thr) && (all || chi < mean))
+                        stage2_kept<PINHOLE>(T, cam, muv[(r * 2 + 0) * NTB + threadIdx.x],
+                                             muv[(r * 2 + 1) * NTB + threadIdx.x], rx[r], ry[r], rz[r], chi,
+                                             kept[(r * 2 + 1) * NTB + threadIdx.x], s);
+                }
+            double vals[S2_USED];
+            pack_sets(s, vals);
+            const double tot = block_sum<S2_USED, NTB>(vals, lds);
+            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = (threadIdx.x < S2_USED) ? tot : 0.0;
+            __syncthreads();
+        } else {
+            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = 0.0; // :300
+            __syncthreads();
+        }
+        double* row = (myhist != nullptr && it < hist_rows) ? myhist + (size_t)it * PICP_HIST_STRIDE : nullptr;
+        (void)solve_step(st, s1, s2, sc, row, &sh);
+    }
+    if (threadIdx.x == 0) {
+        picp_result r;
+        const bool valid = (st[ST_IT] > 0.0) && !(st[ST_BEST_ERR] > 5.0); // src/ProjectiveICP.py:249
+        for (int i = 0; i < 16; ++i) r.T[i] = valid ? st[ST_BEST_T + i] : st[ST_START_T + i];
+        r.valid = valid ? 1 : 0;
+        r.num_iterations = (int)st[ST_IT];
+        r.best_index = (int)st[ST_BEST_IT];
+        r.reserved = 0;
+        r.best_error = st[ST_BEST_ERR];
+        results[prob] = r;
+    }
+}
+
 static CameraK camera_of(const picp_camera* cam) {
     CameraK c;
     for (int i = 0; i < 9; ++i) c.k[i] = cam->K[i];
@@ -365,6 +486,44 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     case 4: launch_resident<4>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
     default: launch_resident<8>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
     }
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+template <int R>
+static void launch_batched(picp_ctx* ctx, int B, const double* u, const double* v, const double* x, const double* y,
+                           const double* z, const int64_t* offsets, const double* poses0, const picp_camera* cam,
+                           const picp_schedule* sched, picp_result* results, double* hist, int hist_rows) {
+    const CameraK c = camera_of(cam);
+    auto kern = is_pinhole(cam->K) ? icp_batched_resident_kernel<R, true> : icp_batched_resident_kernel<R, false>;
+    constexpr unsigned dyn_bytes = R * 4 * NTB * sizeof(double);
+    if (dyn_bytes > 48 * 1024) {
+        static bool raised[2] = {false, false};
+        const int which = is_pinhole(cam->K) ? 1 : 0;
+        if (!raised[which]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)dyn_bytes);
+            raised[which] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NTB), dyn_bytes, ctx->stream, u, v, x, y, z, offsets, poses0, c, *sched, results,
+                       hist, hist_rows);
+}
+
+// Largest problem the on-chip batched kernel takes.
+int64_t batched_resident_capacity() { return (int64_t)NTB * 16; }
+
+// Batch of B problems, none larger than max_count <= batched_resident_capacity().
+int enqueue_batched_resident(picp_ctx* ctx, int B, int64_t max_count, const double* u, const double* v, const double* x,
+                             const double* y, const double* z, const int64_t* offsets, const double* poses0,
+                             const picp_camera* cam, const picp_schedule* sched, picp_result* results, double* hist,
+                             int hist_rows) {
+    const int64_t per = (max_count + NTB - 1) / NTB;
+    if (per <= 1) launch_batched<1>(ctx, B, u, v, x, y, z, offsets, poses0, cam, sched, results, hist, hist_rows);
+    else if (per <= 2) launch_batched<2>(ctx, B, u, v, x, y, z, offsets, poses0, cam, sched, results, hist, hist_rows);
+    else if (per <= 4) launch_batched<4>(ctx, B, u, v, x, y, z, offsets, poses0, cam, sched, results, hist, hist_rows);
+    else if (per <= 8) launch_batched<8>(ctx, B, u, v, x, y, z, offsets, poses0, cam, sched, results, hist, hist_rows);
+    else launch_batched<16>(ctx, B, u, v, x, y, z, offsets, poses0, cam, sched, results, hist, hist_rows);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
 }

@@ -56,22 +56,30 @@ def test_batched_4096_frames_of_2048_correspondences():
         res1, _ = ctx.run_batched(sub, ctx.to_device(np.array([0, N]), np.int64), poses0[:1], cam, sched)
         r1 = ctx.decode_results(res1.cpu().numpy())
         assert np.array_equal(r1["T"][0], r["T"][p])
-    # ragged and empty problems in one batch
-    counts = np.array([0, 1, 9, 10, 11, 300, 2048, 5000, 0, 17])
-    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    rb, hb = ctx.run_batched([c[:offs[-1]] for c in corr], ctx.to_device(offs, np.int64), poses0[:len(counts)], cam,
-                             _cam_sched(12, False)[1], want_history=True)
+    # ragged and empty problems in one batch: the largest problem decides the kernel (5 000: re-read
+    # from memory every iteration; 4 000 and 300: held on chip with 16 / 2 correspondences per thread)
+    for counts in ([0, 1, 9, 10, 11, 300, 2048, 5000, 0, 17], [0, 1, 9, 10, 11, 300, 2048, 4000, 0, 17],
+                   [300, 0, 257, 1, 256]):
+        counts = np.array(counts)
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        rb, hb = ctx.run_batched([c[:offs[-1]] for c in corr], ctx.to_device(offs, np.int64), poses0[:len(counts)], cam,
+                                 _cam_sched(12, False)[1], want_history=True)
+        rr = ctx.decode_results(rb.cpu().numpy())
+        for k, n in enumerate(counts):
+            T_ref, valid_ref, h_ref = po.projective_icp(uv[offs[k]:offs[k + 1]], pw[offs[k]:offs[k + 1]], np.eye(4),
+                                                        po.IcpParams(num_iterations=12))
+            assert bool(rr["valid"][k]) == valid_ref and int(rr["num_iterations"][k]) == len(h_ref["error"]), (k, n)
+            kb = int(rr["best_index"][k])
+            if valid_ref:
+                assert abs(h_ref["error"][kb] - h_ref["error"][h_ref["best_index"]]) <= 1e-9 * h_ref["error"][kb], (k, n)
+                assert rel_err(rr["T"][k], h_ref["T"][kb]) < 1e-9, (k, n)
+            else:
+                assert rel_err(rr["T"][k], T_ref) < 1e-9, (k, n)
+    # a problem larger than the caller's bound is refused, not silently truncated
+    offs = np.array([0, 100, 400], dtype=np.int64)
+    rb, _ = ctx.run_batched([c[:400] for c in corr], ctx.to_device(offs, np.int64), poses0[:2], cam, sched, max_count=128)
     rr = ctx.decode_results(rb.cpu().numpy())
-    for k, n in enumerate(counts):
-        T_ref, valid_ref, h_ref = po.projective_icp(uv[offs[k]:offs[k + 1]], pw[offs[k]:offs[k + 1]], np.eye(4),
-                                                    po.IcpParams(num_iterations=12))
-        assert bool(rr["valid"][k]) == valid_ref and int(rr["num_iterations"][k]) == len(h_ref["error"]), (k, n)
-        kb = int(rr["best_index"][k])
-        if valid_ref:
-            assert abs(h_ref["error"][kb] - h_ref["error"][h_ref["best_index"]]) <= 1e-9 * h_ref["error"][kb], (k, n)
-            assert rel_err(rr["T"][k], h_ref["T"][kb]) < 1e-9, (k, n)
-        else:
-            assert rel_err(rr["T"][k], T_ref) < 1e-9, (k, n)
+    assert int(rr["num_iterations"][0]) == 20 and int(rr["num_iterations"][1]) == -1 and not rr["valid"][1]
 
 
 @pytest.mark.parametrize("mode", ["scan", "auto"])

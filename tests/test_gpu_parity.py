@@ -194,8 +194,11 @@ def test_gtmap_icp_120_frames_kernel_path(ctx, bundled, loop_path):
                    g["T"][offs[f]:offs[f + 1]], g["T_out"][f])
 
 
-def test_gtmap_icp_120_frames_batched(ctx, bundled):
-    """All 120 frame problems in ONE launch, one workgroup per frame, whole loop inside the kernel."""
+@pytest.mark.parametrize("max_count", [None, 0], ids=["on_chip", "reread"])
+def test_gtmap_icp_120_frames_batched(ctx, bundled, max_count):
+    """All 120 frame problems in ONE launch, one workgroup per frame, whole loop inside the kernel:
+    with a bound on the problem size the correspondences stay in registers/LDS, without one
+    (max_count = 0) they are re-read every iteration."""
     g = load_golden("ref_gtmap_icp.npz")
     cam, sched = bundled_cam(), yaml_sched()
     offs = g["iter_offsets"]
@@ -204,7 +207,8 @@ def test_gtmap_icp_120_frames_batched(ctx, bundled):
     offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     corr = ctx.soa(np.concatenate(uvs), np.concatenate(pws))
     results, hist = ctx.run_batched(corr, ctx.to_device(offsets, np.int64),
-                                    ctx.to_device(g["start_pose"].reshape(120, 16)), cam, sched, want_history=True)
+                                    ctx.to_device(g["start_pose"].reshape(120, 16)), cam, sched, want_history=True,
+                                    max_count=max_count)
     r = ctx.decode_results(results.cpu().numpy())
     hist = hist.cpu().numpy()
     for f in range(120):
