@@ -45,6 +45,7 @@ constexpr int NTR = 512;                 // eight waves: two per SIMD
 constexpr int RW = PICP_S2_DOUBLES;      // doubles per exchange record (both stages use one slot layout)
 constexpr int R_MAX = 8;                 // correspondences per thread
 constexpr int SLOTS = 3;
+constexpr int MAX_DEVICES = 64;           // per-device bookkeeping of kernel attributes
 constexpr int MAX_GRID = 256;            // rows one fold covers with all of a thread's loads in flight
 constexpr unsigned long long SENTINEL_BITS = 0xFFF8C0DEC0DE5EEDull; // a NaN payload arithmetic never produces
 
@@ -439,13 +440,13 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
     GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
     auto kern = is_pinhole(cam->K) ? icp_resident_kernel<R, true> : icp_resident_kernel<R, false>;
     constexpr unsigned kept_bytes = R * 4 * NTR * sizeof(double); // u, v, chi, 1/z per correspondence
-    if (kept_bytes > 48 * 1024) { // above the default dynamic-LDS allowance: raise it once per kernel
-        static bool raised[2] = {false, false};
+    if (kept_bytes > 48 * 1024) { // above the default dynamic-LDS allowance: raise it once per kernel and device
+        static bool raised[2][MAX_DEVICES] = {};
         const int which = is_pinhole(cam->K) ? 1 : 0;
-        if (!raised[which]) {
+        if (ctx->device >= MAX_DEVICES || !raised[which][ctx->device]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)kept_bytes);
-            raised[which] = true;
+            if (ctx->device < MAX_DEVICES) raised[which][ctx->device] = true;
         }
     }
     if (e0 != nullptr)
@@ -498,12 +499,12 @@ static void launch_batched(picp_ctx* ctx, int B, const double* u, const double* 
     auto kern = is_pinhole(cam->K) ? icp_batched_resident_kernel<R, true> : icp_batched_resident_kernel<R, false>;
     constexpr unsigned dyn_bytes = R * 4 * NTB * sizeof(double);
     if (dyn_bytes > 48 * 1024) {
-        static bool raised[2] = {false, false};
+        static bool raised[2][MAX_DEVICES] = {};
         const int which = is_pinhole(cam->K) ? 1 : 0;
-        if (!raised[which]) {
+        if (ctx->device >= MAX_DEVICES || !raised[which][ctx->device]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)dyn_bytes);
-            raised[which] = true;
+            if (ctx->device < MAX_DEVICES) raised[which][ctx->device] = true;
         }
     }
     hipLaunchKernelGGL(kern, dim3(B), dim3(NTB), dyn_bytes, ctx->stream, u, v, x, y, z, offsets, poses0, c, *sched, results,
