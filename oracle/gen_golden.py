@@ -337,15 +337,79 @@ def gen_association(ref_da, cam):
     print("association: matches", len(m0["points_1"]), len(m1["points_1"]), len(m2["points_1"]))
 
 
+# --------------------------------------------------------------------------
+# 6. a camera matrix that is not of pinhole shape (skew, unequal focal lengths, a
+#    non-zero entry in the last row): the reference reads whatever data/camera.dat holds
+#    (src/Camera.py:20-24, integers), and the device code has a separate instantiation
+#    for matrices with non-zero off-diagonal entries.
+# --------------------------------------------------------------------------
+GENERAL_K = [[180, 3, 320], [-2, 170, 240], [0, 0, 1]]
+
+
+def gen_general_camera(ref_picp_mod, Camera, Data, geo):
+    scratch = tempfile.mkdtemp(prefix="picp_golden_cam_")
+    os.makedirs(os.path.join(scratch, "data"))
+    for name in os.listdir(os.path.join(REF, "data")):
+        if name != "camera.dat":
+            os.symlink(os.path.join(REF, "data", name), os.path.join(scratch, "data", name))
+    lines = open(os.path.join(REF, "data", "camera.dat")).read().split("\n")
+    k = next(i for i, line in enumerate(lines) if line.startswith("camera matrix"))
+    for r in range(3):
+        lines[k + 1 + r] = " ".join(str(x) for x in GENERAL_K[r])
+    with open(os.path.join(scratch, "data", "camera.dat"), "w") as fh:
+        fh.write("\n".join(lines))
+    back = os.getcwd()
+    os.chdir(scratch)
+    try:
+        cam, data = Camera(), Data()
+        K = np.array(cam.get_camera_matrix(), dtype=np.float64)
+        assert np.array_equal(K, np.array(GENERAL_K, dtype=np.float64))
+        rng = np.random.default_rng(42)
+        out = {"K": K}
+        T_true = geo.v2T([0.05, -0.03, 0.2, 0.01, -0.02, 0.015])
+        c_T_w = np.linalg.inv(T_true)
+        loops = [(400, np.eye(4), {}), (37, geo.v2T([0.2, -0.1, 0.1, 0.03, 0.02, -0.04]), {"num_iterations": 40})]
+        for li, (M, pose, over) in enumerate(loops):
+            z = rng.uniform(1.0, 20.0, M)
+            pix = np.stack([rng.uniform(40, 600, M), rng.uniform(40, 440, M), np.ones(M)], axis=1)
+            pw = (np.linalg.inv(K) @ pix.T).T * z[:, None]            # in the image under the identity pose
+            pc = (c_T_w[:3, :3] @ pw.T).T + c_T_w[:3, 3]
+            h = (K @ pc.T).T
+            uv = h[:, :2] / h[:, 2:3] + rng.normal(0, 0.5, (M, 2))
+            no = M // 10
+            idx = rng.choice(M, no, replace=False)
+            uv[idx] = np.stack([rng.uniform(0, 640, no), rng.uniform(0, 480, no)], axis=1)
+            lp = make_picp(ref_picp_mod, cam, data, **over)
+            m = lp.get_map()
+            app = rng.uniform(-1, 1, (M, 10))
+            m["position"] = [p for p in pw]
+            m["appearance"] = [list(a) for a in app]
+            m["error"] = [0.0] * M
+            meas = {"position": [list(p) for p in uv], "appearance": [list(a) for a in app]}
+            r = run_icp_capture(ref_picp_mod, lp, cam, pose, meas, 0)
+            out.update({f"loop{li}_uv": uv, f"loop{li}_pw": pw, f"loop{li}_pose": pose,
+                        f"loop{li}_num_iterations": over.get("num_iterations", YAML["num_iterations"])})
+            out.update({f"loop{li}_{k}": v for k, v in r.items()})
+        out["n_loops"] = len(loops)
+        np.savez_compressed(os.path.join(OUT, "ref_general_camera.npz"), **out)
+        print("general camera: loops", len(loops), [len(out[f"loop{li}_error"]) for li in range(len(loops))])
+    finally:
+        os.chdir(back)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_picp_mod, Camera, Data, ref_da, ref_geo = import_reference()
+    if "--only-general-camera" in sys.argv:
+        gen_general_camera(ref_picp_mod, Camera, Data, ref_geo)
+        return
     cam, data = Camera(), Data()
     pack_bundled(cam, data)
     gen_v2T(ref_geo)
     gen_association(ref_da, cam)
     gen_synthetic(ref_picp_mod, cam, data, ref_geo)
     gen_gtmap(ref_picp_mod, cam, data)
+    gen_general_camera(ref_picp_mod, Camera, Data, ref_geo)
 
 
 if __name__ == "__main__":

@@ -140,10 +140,10 @@ def test_linearize_edge_cases(ctx):
         assert abs(err - g[f"edge{ti}_err"]) <= TOL * abs(g[f"edge{ti}_err"])
 
 
-@pytest.mark.parametrize("path", ["kernels", "workgroup"])
+@pytest.mark.parametrize("path", ["kernels", "workgroup", "workgroup_reread"])
 def test_full_loop_reference_synthetic(ctx, path, loop_path):
-    if path == "workgroup" and loop_path == "resident":
-        pytest.skip("the batched kernel has one device path")
+    if path != "kernels" and loop_path == "resident":
+        pytest.skip("the batched kernels do not depend on picp_run's path")
     g = load_golden("ref_synthetic.npz")
     cam = bundled_cam()
     for li in range(int(g["n_loops"])):
@@ -156,7 +156,38 @@ def test_full_loop_reference_synthetic(ctx, path, loop_path):
         else:
             M = len(g[f"{pre}uv"])
             results, h = ctx.run_batched(corr, ctx.to_device(np.array([0, M]), np.int64),
-                                         ctx.to_device(g[f"{pre}pose"].reshape(1, 16)), cam, sched, want_history=True)
+                                         ctx.to_device(g[f"{pre}pose"].reshape(1, 16)), cam, sched, want_history=True,
+                                         max_count=None if path == "workgroup" else 0)
+            r = ctx.decode_results(results.cpu().numpy())
+            hist = h[0, : r["num_iterations"][0]].cpu().numpy()
+            T, valid, best = r["T"][0], bool(r["valid"][0]), int(r["best_index"][0])
+        check_history(hist, g, pre)
+        assert valid == bool(g[f"{pre}valid"])
+        if valid:
+            check_best(T, best, g[f"{pre}error"], g[f"{pre}T"], g[f"{pre}T_out"])
+        else:
+            assert rel_err(T, g[f"{pre}T_out"]) < TOL
+
+
+@pytest.mark.parametrize("path", ["run", "batched_on_chip", "batched_reread"])
+def test_full_loop_general_camera_matrix(ctx, path, loop_path):
+    """A camera matrix with skew and unequal focal lengths takes the kernels' general-K instantiations."""
+    if path != "run" and loop_path == "resident":
+        pytest.skip("the batched kernels do not depend on picp_run's path")
+    g = load_golden("ref_general_camera.npz")
+    cam = L.camera_struct(g["K"], 640, 480)
+    for li in range(int(g["n_loops"])):
+        pre = f"loop{li}_"
+        sched = yaml_sched(int(g[f"{pre}num_iterations"]))
+        corr = ctx.soa(g[f"{pre}uv"], g[f"{pre}pw"])
+        if path == "run":
+            res, hist = ctx.run(corr, g[f"{pre}pose"], cam, sched)
+            T, valid, best = np.array(list(res.T)).reshape(4, 4), bool(res.valid), res.best_index
+        else:
+            M = len(g[f"{pre}uv"])
+            results, h = ctx.run_batched(corr, ctx.to_device(np.array([0, M]), np.int64),
+                                         ctx.to_device(g[f"{pre}pose"].reshape(1, 16)), cam, sched, want_history=True,
+                                         max_count=None if path == "batched_on_chip" else 0)
             r = ctx.decode_results(results.cpu().numpy())
             hist = h[0, : r["num_iterations"][0]].cpu().numpy()
             T, valid, best = r["T"][0], bool(r["valid"][0]), int(r["best_index"][0])

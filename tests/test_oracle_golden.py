@@ -97,6 +97,19 @@ def test_full_loop_synthetic():
         assert rel_err(T, g[f"{pre}T_out"]) < TOL
 
 
+def test_full_loop_general_camera_matrix():
+    """The reference with a camera matrix that has skew and unequal focal lengths (it reads whatever
+    data/camera.dat holds, src/Camera.py:20-24)."""
+    g = load_golden("ref_general_camera.npz")
+    for li in range(int(g["n_loops"])):
+        pre = f"loop{li}_"
+        params = po.IcpParams(K=g["K"], num_iterations=int(g[f"{pre}num_iterations"]))
+        T, valid, hist = po.projective_icp(g[f"{pre}uv"], g[f"{pre}pw"], g[f"{pre}pose"], params, record_linear=True)
+        _check_loop(hist, T, valid, g, pre)
+        assert valid == bool(g[f"{pre}valid"])
+        assert rel_err(T, g[f"{pre}T_out"]) < TOL
+
+
 def test_gtmap_icp_all_120_frames(bundled):
     """The reference's LM loop on the bundled measurements with the ground-truth map: 1 574 iterations
     over 120 frame pairs, covering zero-inlier iterations and every schedule branch."""
