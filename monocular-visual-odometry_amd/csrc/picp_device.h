@@ -94,21 +94,25 @@ struct Projected {
     bool inside;
 };
 
+// The arithmetic is spelled out (fused multiply-adds in a fixed order, no compiler contraction):
+// every kernel must get the same bits for the same point, because one kernel's chi is compared
+// with a mean formed from another kernel's chi of the same points (src/ProjectiveICP.py:302).
 template <bool PINHOLE>
 __device__ __forceinline__ Projected project_point(const double* __restrict__ T, const CameraK& cam, double x,
                                                    double y, double z) {
+#pragma clang fp contract(off)
     Projected p;
-    p.pcx = T[0] * x + T[1] * y + T[2] * z + T[3];
-    p.pcy = T[4] * x + T[5] * y + T[6] * z + T[7];
-    p.pcz = T[8] * x + T[9] * y + T[10] * z + T[11];
+    p.pcx = __builtin_fma(T[2], z, __builtin_fma(T[1], y, T[0] * x)) + T[3];
+    p.pcy = __builtin_fma(T[6], z, __builtin_fma(T[5], y, T[4] * x)) + T[7];
+    p.pcz = __builtin_fma(T[10], z, __builtin_fma(T[9], y, T[8] * x)) + T[11];
     if (PINHOLE) {
-        p.h0 = cam.k[0] * p.pcx + cam.k[2] * p.pcz;
-        p.h1 = cam.k[4] * p.pcy + cam.k[5] * p.pcz;
+        p.h0 = __builtin_fma(cam.k[2], p.pcz, cam.k[0] * p.pcx);
+        p.h1 = __builtin_fma(cam.k[5], p.pcz, cam.k[4] * p.pcy);
         p.h2 = cam.k[8] * p.pcz;
     } else {
-        p.h0 = cam.k[0] * p.pcx + cam.k[1] * p.pcy + cam.k[2] * p.pcz;
-        p.h1 = cam.k[3] * p.pcx + cam.k[4] * p.pcy + cam.k[5] * p.pcz;
-        p.h2 = cam.k[6] * p.pcx + cam.k[7] * p.pcy + cam.k[8] * p.pcz;
+        p.h0 = __builtin_fma(cam.k[2], p.pcz, __builtin_fma(cam.k[1], p.pcy, cam.k[0] * p.pcx));
+        p.h1 = __builtin_fma(cam.k[5], p.pcz, __builtin_fma(cam.k[4], p.pcy, cam.k[3] * p.pcx));
+        p.h2 = __builtin_fma(cam.k[8], p.pcz, __builtin_fma(cam.k[7], p.pcy, cam.k[6] * p.pcx));
     }
     p.zi = 1.0 / p.h2; // also z_inv of the Jacobian (src/ProjectiveICP.py:345)
     p.u = div_with_recip(p.h0, p.h2, p.zi);
@@ -118,9 +122,9 @@ __device__ __forceinline__ Projected project_point(const double* __restrict__ T,
     if (!safe) {
         // Extreme magnitudes, infinities or NaN (never the case for real map points): the full
         // products with K (0 * inf is NaN, so K's zero entries matter here) and plain IEEE divisions.
-        p.h0 = cam.k[0] * p.pcx + cam.k[1] * p.pcy + cam.k[2] * p.pcz;
-        p.h1 = cam.k[3] * p.pcx + cam.k[4] * p.pcy + cam.k[5] * p.pcz;
-        p.h2 = cam.k[6] * p.pcx + cam.k[7] * p.pcy + cam.k[8] * p.pcz;
+        p.h0 = __builtin_fma(cam.k[2], p.pcz, __builtin_fma(cam.k[1], p.pcy, cam.k[0] * p.pcx));
+        p.h1 = __builtin_fma(cam.k[5], p.pcz, __builtin_fma(cam.k[4], p.pcy, cam.k[3] * p.pcx));
+        p.h2 = __builtin_fma(cam.k[8], p.pcz, __builtin_fma(cam.k[7], p.pcy, cam.k[6] * p.pcx));
         p.zi = 1.0 / p.h2;
         p.u = p.h0 / p.h2;
         p.v = p.h1 / p.h2;
@@ -129,6 +133,15 @@ __device__ __forceinline__ Projected project_point(const double* __restrict__ T,
     const bool outside = (p.u < 0.0) || (p.u >= cam.width) || (p.v < 0.0) || (p.v >= cam.height);
     p.inside = !behind && !outside;
     return p;
+}
+
+// chi = e^T e (src/ProjectiveICP.py:293).  numpy evaluates the 2-vector product as
+// fma(e1, e1, e0 * e0) (its BLAS dot kernel accumulates with fused multiply-adds; checked against
+// `e.T @ e` on the build host); the same expression here, so that a chi that sits exactly on the
+// threshold or on the mean falls on the same side as in the reference.
+__device__ __forceinline__ double chi_of(double e0, double e1) {
+#pragma clang fp contract(off)
+    return __builtin_fma(e1, e1, e0 * e0);
 }
 
 // ---- __error_and_jacobian (src/ProjectiveICP.py:326-353) ------------------------------------
@@ -846,7 +859,7 @@ __device__ __forceinline__ void stage1_point(const double* __restrict__ T, const
                                              double mv, double x, double y, double z, Stage1Sums& s) {
     const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
     const double e0 = mu - p.u, e1 = mv - p.v;         // src/ProjectiveICP.py:333
-    const double chi = e0 * e0 + e1 * e1;              // :293
+    const double chi = chi_of(e0, e1);                 // :293
     const bool keep = p.inside && (chi <= thr);        // :290, :294
     s.n_inside += p.inside ? 1u : 0u;
     s.n1 += keep ? 1u : 0u;
@@ -872,7 +885,7 @@ __device__ __forceinline__ void stage2_point(const double* __restrict__ T, const
                                              Stage2Sums& s) {
     const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
     const double e0 = mu - p.u, e1 = mv - p.v;
-    const double chi = e0 * e0 + e1 * e1;
+    const double chi = chi_of(e0, e1);
     const bool keep = p.inside && (chi <= thr) && (all || chi < mean);
     if (keep) {
         double J0[6], J1[6];

@@ -147,7 +147,7 @@ __device__ __forceinline__ void stage1_keep(const double* __restrict__ T, const 
                                             double mv, double x, double y, double z, Stage1Sums& s, double (&keep)[2]) {
     const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
     const double e0 = mu - p.u, e1 = mv - p.v;         // src/ProjectiveICP.py:333
-    const double chi = e0 * e0 + e1 * e1;              // :293
+    const double chi = chi_of(e0, e1);                 // :293
     const bool in1 = p.inside && (chi <= thr);         // :290, :294
     s.n_inside += p.inside ? 1u : 0u;
     s.n1 += in1 ? 1u : 0u;
@@ -163,18 +163,19 @@ __device__ __forceinline__ void stage1_keep(const double* __restrict__ T, const 
 template <bool PINHOLE>
 __device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const CameraK& cam, double mu, double mv,
                                             double x, double y, double z, double chi, double zi, Stage2Sums& s) {
+#pragma clang fp contract(off)
     Projected p;
-    p.pcx = T[0] * x + T[1] * y + T[2] * z + T[3];
-    p.pcy = T[4] * x + T[5] * y + T[6] * z + T[7];
-    p.pcz = T[8] * x + T[9] * y + T[10] * z + T[11];
+    p.pcx = __builtin_fma(T[2], z, __builtin_fma(T[1], y, T[0] * x)) + T[3];
+    p.pcy = __builtin_fma(T[6], z, __builtin_fma(T[5], y, T[4] * x)) + T[7];
+    p.pcz = __builtin_fma(T[10], z, __builtin_fma(T[9], y, T[8] * x)) + T[11];
     if (PINHOLE) {
-        p.h0 = cam.k[0] * p.pcx + cam.k[2] * p.pcz;
-        p.h1 = cam.k[4] * p.pcy + cam.k[5] * p.pcz;
+        p.h0 = __builtin_fma(cam.k[2], p.pcz, cam.k[0] * p.pcx);
+        p.h1 = __builtin_fma(cam.k[5], p.pcz, cam.k[4] * p.pcy);
         p.h2 = cam.k[8] * p.pcz;
     } else {
-        p.h0 = cam.k[0] * p.pcx + cam.k[1] * p.pcy + cam.k[2] * p.pcz;
-        p.h1 = cam.k[3] * p.pcx + cam.k[4] * p.pcy + cam.k[5] * p.pcz;
-        p.h2 = cam.k[6] * p.pcx + cam.k[7] * p.pcy + cam.k[8] * p.pcz;
+        p.h0 = __builtin_fma(cam.k[2], p.pcz, __builtin_fma(cam.k[1], p.pcy, cam.k[0] * p.pcx));
+        p.h1 = __builtin_fma(cam.k[5], p.pcz, __builtin_fma(cam.k[4], p.pcy, cam.k[3] * p.pcx));
+        p.h2 = __builtin_fma(cam.k[8], p.pcz, __builtin_fma(cam.k[7], p.pcy, cam.k[6] * p.pcx));
     }
     const double e0 = mu - div_with_recip(p.h0, p.h2, zi);
     const double e1 = mv - div_with_recip(p.h1, p.h2, zi);

@@ -174,7 +174,9 @@ def linearize(uv_meas, pw, kernel_threshold, w_T_c0, params: IcpParams, c_T_w=No
     H = np.zeros((6, 6))
     b = np.zeros(6)
     with np.errstate(invalid="ignore"):
-        chi = e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]                     # :293
+        # :293 `error.T @ error`: numpy's dot of a 2-vector is fma(e1, e1, e0 * e0) on this build; the
+        # batched matrix product goes through the same BLAS kernel and reproduces it bit for bit
+        chi = (e[:, None, :] @ e[:, :, None]).reshape(-1)
         keep1 = inside & (chi <= kernel_threshold)                      # :290, :294
     aux = {"n_inside": int(inside.sum()), "n_stage1": int(keep1.sum()), "n_stage2": 0,
            "used_stage2": False}

@@ -44,7 +44,7 @@ class NumpyStages:
     def _terms(self):
         inside, e, J = po.errors_and_jacobians(self.uv, self.pw, self.w_T_c, self.p, self.c_T_w)
         with np.errstate(invalid="ignore"):
-            chi = e[:, 0] ** 2 + e[:, 1] ** 2
+            chi = (e[:, None, :] @ e[:, :, None]).reshape(-1)     # as picp_oracle.linearize (:293)
             keep = inside & (chi <= self.thr)
         return inside, e, J, chi, keep
 

@@ -387,3 +387,38 @@ def test_single_launch_loop_gives_up_cleanly(monkeypatch):
         assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h_ref["num_inliers"]))
         assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
     assert impatient.resident_aborts() >= 1
+
+
+def test_single_launch_loop_equals_streaming_loop_on_random_problems(ctx):
+    """picp_run's two device paths on 150 random problems (sizes 1 .. 60 000, good and bad start poses,
+    tight and loose thresholds, so that zero-inlier iterations, the fallback to the stage-1 set and
+    early stops all occur): identical iteration counts, inlier counts, thresholds and damping; poses
+    within 1e-9."""
+    rng = np.random.default_rng(2024)
+    cam = bundled_cam()
+    seen_redo = seen_zero = 0
+    try:
+        for k in range(150):
+            M = int(rng.choice([1, 7, 12, 40, 300, 2000, 9000, 60000]))
+            uv, pw, _ = make_problem(M, seed=1000 + k, outlier_frac=float(rng.choice([0.0, 0.1, 0.6])))
+            start = po.v2T(rng.normal(0, 1, 6) * np.array([0.3, 0.3, 0.3, 0.05, 0.05, 0.05]) * float(rng.choice([0.1, 1, 4])))
+            sched = yaml_sched(int(rng.choice([5, 40, 120])), kernel_threshold=float(rng.choice([0.5, 30, 1000])),
+                               min_inliers=int(rng.choice([3, 10, 200])))
+            corr = ctx.soa(uv, pw)
+            ctx.set_resident_limit(0)
+            res_s, hist_s = ctx.run(corr, start, cam, sched)
+            ctx.set_resident_limit(None)
+            res_r, hist_r = ctx.run(corr, start, cam, sched)
+            assert res_r.num_iterations == res_s.num_iterations, k
+            assert bool(res_r.valid) == bool(res_s.valid), k
+            for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_KERNEL_THR, L.H_DAMPING, L.H_N_STAGE1, L.H_N_STAGE2,
+                        L.H_USED_STAGE2, L.H_DONE):
+                assert np.array_equal(hist_r[:, col], hist_s[:, col]), (k, col)
+            assert rel_err(hist_r[:, L.H_T:L.H_T + 16], hist_s[:, L.H_T:L.H_T + 16]) < TOL, k
+            if res_r.best_index == res_s.best_index:
+                assert rel_err(np.array(list(res_r.T)), np.array(list(res_s.T))) < TOL, k
+            seen_redo += int(np.any((hist_s[:, L.H_USED_STAGE2] == 0) & (hist_s[:, L.H_N_STAGE1] > 0)))
+            seen_zero += int(np.any(hist_s[:, L.H_NUM_INLIERS] == 0))
+    finally:
+        ctx.set_resident_limit(None)
+    assert seen_redo > 0 and seen_zero > 0      # the rare branches were exercised
