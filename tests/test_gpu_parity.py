@@ -422,3 +422,30 @@ def test_single_launch_loop_equals_streaming_loop_on_random_problems(ctx):
     finally:
         ctx.set_resident_limit(None)
     assert seen_redo > 0 and seen_zero > 0      # the rare branches were exercised
+
+
+def test_random_problems_against_oracle(ctx, loop_path):
+    """80 random problems (sizes 1 .. 9 000, random start poses, thresholds and inlier minimum, stop
+    test on) against the numpy restatement: iteration counts, in-image and inlier counts, thresholds
+    and damping identical; poses within 1e-9."""
+    rng = np.random.default_rng(77)
+    cam = bundled_cam()
+    for k in range(80):
+        M = int(rng.choice([1, 2, 7, 12, 40, 300, 2000, 9000]))
+        uv, pw, _ = make_problem(M, seed=5000 + k, outlier_frac=float(rng.choice([0.0, 0.1, 0.6])))
+        start = po.v2T(rng.normal(0, 1, 6) * np.array([0.3, 0.3, 0.3, 0.05, 0.05, 0.05]) * float(rng.choice([0.1, 1, 4])))
+        n_it, thr, min_inl = int(rng.choice([5, 40, 90])), float(rng.choice([0.5, 30, 1000])), int(rng.choice([1, 3, 10, 200]))
+        params = po.IcpParams(num_iterations=n_it, kernel_threshold=thr, min_inliers=min_inl)
+        T_ref, valid_ref, h = po.projective_icp(uv, pw, start, params, record_linear=True)
+        res, hist = ctx.run(ctx.soa(uv, pw), start, cam, yaml_sched(n_it, kernel_threshold=thr, min_inliers=min_inl))
+        assert res.num_iterations == len(h["error"]), k
+        assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h["num_inliers"])), k
+        assert np.array_equal(hist[:, L.H_N_INSIDE].astype(np.int64), np.array(h["n_inside"])), k
+        assert np.array_equal(hist[:, L.H_KERNEL_THR], np.array(h["kernel_threshold"], dtype=np.float64)), k
+        assert np.array_equal(hist[:, L.H_DAMPING], np.array(h["dumping_factor"], dtype=np.float64)), k
+        assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(h["T"])) < TOL, k
+        assert bool(res.valid) == valid_ref, k
+        if valid_ref:
+            check_best(np.array(list(res.T)).reshape(4, 4), res.best_index, np.array(h["error"]), np.array(h["T"]), T_ref)
+        else:
+            assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL, k
