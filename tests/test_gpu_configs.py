@@ -1,5 +1,5 @@
 """The benchmark configurations that are not bench lines, at their full sizes, checked through
-properties and samples (BASELINE configs 3 and 5, and the 2^20 single-pose loop's invariances)."""
+properties and samples (the batched and association configurations, and the 2^20 single-pose loop's invariances)."""
 import importlib
 
 import numpy as np
