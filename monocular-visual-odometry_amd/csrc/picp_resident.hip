@@ -1,8 +1,8 @@
 // The whole pose loop in ONE launch with the correspondences held in registers.
 //
 // When M correspondences fit the register files of the chip (one 512-thread workgroup per CU, up to
-// R_MAX correspondences per thread), the five input arrays are read from HBM once; every
-// iteration then works on registers.  The two device-wide sums an iteration needs
+// R_MAX correspondences per thread: 2^21 on 256 CUs), the five input arrays are read from HBM once;
+// every iteration then works on registers and LDS.  The two device-wide sums an iteration needs
 // (src/ProjectiveICP.py:301 needs the mean of chi over all stage-1 survivors before the inlier set
 // of :302-310 can be chosen, and :313-317 sum H and b over that set) are exchanged between the
 // workgroups through small records in global memory:
@@ -43,7 +43,8 @@ namespace picp {
 
 constexpr int NTR = 512;                 // eight waves: two per SIMD
 constexpr int RW = PICP_S2_DOUBLES;      // doubles per exchange record (both stages use one slot layout)
-constexpr int R_MAX = 8;                 // correspondences per thread
+constexpr int R_MAX = 16;                // correspondences per thread
+constexpr int R_KEEP_MAX = 8;            // up to here LDS also keeps stage 1's chi and 1/z for stage 2
 constexpr int SLOTS = 3;
 constexpr int MAX_DEVICES = 64;           // per-device bookkeeping of kernel attributes
 constexpr int MAX_GRID = 256;            // rows one fold covers with all of a thread's loads in flight
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     // (they are only read, once or twice per iteration, so they need not occupy registers) and the
     // stage-1 results kept for stage 2 (chi, 1/z) as [R][2][NTR].
     extern __shared__ double dyn[];
+    constexpr bool KEEP = (R <= R_KEEP_MAX); // above that LDS only has room for u, v: stage 2 projects again
     double* muv = dyn;
     double* kept = dyn + R * 2 * NTR;
 
@@ -246,8 +248,10 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
                 double keep[2];
                 stage1_keep<PINHOLE>(T, cam, thr, muv[(r * 2 + 0) * NTR + threadIdx.x],
                                      muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], a, keep);
-                kept[(r * 2 + 0) * NTR + threadIdx.x] = keep[0];
-                kept[(r * 2 + 1) * NTR + threadIdx.x] = keep[1];
+                if (KEEP) {
+                    kept[(r * 2 + 0) * NTR + threadIdx.x] = keep[0];
+                    kept[(r * 2 + 1) * NTR + threadIdx.x] = keep[1];
+                }
             }
         {
             const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
@@ -265,12 +269,17 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (r < mine) {
-                    const double chi = kept[(r * 2 + 0) * NTR + threadIdx.x];
-                    // NaN (rejected by stage 1) fails both tests; `all`: the stage-1 set, else chi < mean (:302)
-                    if ((chi <= thr) && (all || chi < mean))
-                        stage2_kept<PINHOLE>(T, cam, muv[(r * 2 + 0) * NTR + threadIdx.x],
-                                             muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], chi,
-                                             kept[(r * 2 + 1) * NTR + threadIdx.x], s);
+                    if (KEEP) {
+                        const double chi = kept[(r * 2 + 0) * NTR + threadIdx.x];
+                        // NaN (rejected by stage 1) fails both tests; `all`: the stage-1 set, else chi < mean (:302)
+                        if ((chi <= thr) && (all || chi < mean))
+                            stage2_kept<PINHOLE>(T, cam, muv[(r * 2 + 0) * NTR + threadIdx.x],
+                                                 muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], chi,
+                                                 kept[(r * 2 + 1) * NTR + threadIdx.x], s);
+                    } else {
+                        stage2_point<PINHOLE>(T, cam, thr, mean, all, muv[(r * 2 + 0) * NTR + threadIdx.x],
+                                              muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], s);
+                    }
                 }
             double vals[S2_USED];
             pack_sets(s, vals);
@@ -440,7 +449,7 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
     const CameraK c = camera_of(cam);
     GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
     auto kern = is_pinhole(cam->K) ? icp_resident_kernel<R, true> : icp_resident_kernel<R, false>;
-    constexpr unsigned kept_bytes = R * 4 * NTR * sizeof(double); // u, v, chi, 1/z per correspondence
+    constexpr unsigned kept_bytes = R * (R <= R_KEEP_MAX ? 4 : 2) * NTR * sizeof(double); // u, v (, chi, 1/z)
     if (kept_bytes > 48 * 1024) { // above the default dynamic-LDS allowance: raise it once per kernel and device
         static bool raised[2][MAX_DEVICES] = {};
         const int which = is_pinhole(cam->K) ? 1 : 0;
@@ -472,7 +481,7 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     // workgroups than that R needs
     const int64_t lanes = (int64_t)resident_grid(ctx) * NTR;
     const int64_t per_thread = (M + lanes - 1) / lanes;
-    const int R = per_thread <= 1 ? 1 : (per_thread <= 2 ? 2 : (per_thread <= 4 ? 4 : 8));
+    const int R = per_thread <= 1 ? 1 : (per_thread <= 2 ? 2 : (per_thread <= 4 ? 4 : (per_thread <= 8 ? 8 : 16)));
     const int grid = (int)((M + (int64_t)NTR * R - 1) / ((int64_t)NTR * R));
     PICP_REQUIRE(grid >= 1 && grid <= resident_grid(ctx), "resident loop: grid %d does not fit %d CUs", grid,
                  resident_grid(ctx));
@@ -486,7 +495,8 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     case 1: launch_resident<1>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
     case 2: launch_resident<2>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
     case 4: launch_resident<4>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
-    default: launch_resident<8>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
+    case 8: launch_resident<8>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
+    default: launch_resident<16>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
     }
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
