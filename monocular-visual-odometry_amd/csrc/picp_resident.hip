@@ -46,6 +46,7 @@ constexpr int RW = PICP_S2_DOUBLES;      // doubles per exchange record (both st
 constexpr int R_MAX = 16;                // correspondences per thread
 constexpr int R_KEEP_MAX = 8;            // up to here LDS also keeps stage 1's chi and 1/z for stage 2
 constexpr int SLOTS = 3;
+constexpr int FIRST_LOOK_DELAY = 16;      // s_sleep units (64 clocks) between publishing and the first poll
 constexpr int MAX_DEVICES = 64;           // per-device bookkeeping of kernel attributes
 constexpr int MAX_GRID = 256;            // rows one fold covers with all of a thread's loads in flight
 constexpr unsigned long long SENTINEL_BITS = 0xFFF8C0DEC0DE5EEDull; // a NaN payload arithmetic never produces
@@ -106,6 +107,11 @@ __device__ __forceinline__ bool grid_total(double mine, double& out, const GridE
     }
     // collect: thread (grp, col) owns rows grp, grp + GR, ... of column col
     const int col = threadIdx.x % CW, grp = threadIdx.x / CW;
+    // A record cannot be visible sooner than a store-to-memory plus a load-from-memory latency after
+    // it was published, and loads issued before that only compete with the stores for the memory
+    // channels: a short pause before the first look (about 0.4 us; swept 0 .. 1.7 us on 8 .. 256
+    // workgroups) shortens the whole exchange by 0.4 - 0.5 us.
+    __builtin_amdgcn_s_sleep(FIRST_LOOK_DELAY);
     Fold f;
 #pragma unroll
     for (int k = 0; k < B; ++k) {
