@@ -323,7 +323,9 @@ __device__ __forceinline__ double wave_column_sums(double (&v)[N]) {
 // lds: at least (NT/64)*64 doubles.  On return every thread with tid < NV holds the workgroup
 // total of value tid (other threads: unspecified).  Fixed order of additions: wave_column_sums
 // inside each wave, then waves 0,1,2,.. in order.
-template <int NV, int NT>
+// TRAILING_SYNC = false leaves out the final barrier: the caller must not write `lds` again before
+// its next workgroup barrier.
+template <int NV, int NT, bool TRAILING_SYNC = true>
 __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* lds) {
     static_assert(NV <= 64, "one lane per value");
     const int lane = threadIdx.x & 63;
@@ -356,7 +358,7 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
             for (int w = 0; w < NT / 64; ++w) out += lds[w * 64 + threadIdx.x];
         }
     }
-    __syncthreads();
+    if (TRAILING_SYNC) __syncthreads();
     return out;
 }
 
@@ -407,6 +409,35 @@ struct PartialFold {
             for (int g = 0; g < 64 / CW; ++g) out += lds[g * CW + threadIdx.x];
         }
         __syncthreads();
+        return out;
+    }
+    // Same result layout as finish() for values already in v[] (no further rows), with one barrier:
+    // the row groups of a wave are first added inside the wave (lane swaps for bits 5 and 4, row
+    // shifts for the two bits below when a record is only four wide), then the waves through LDS.
+    // lds: NT/64 * CW doubles, not written again by the caller before its next barrier.
+    __device__ __forceinline__ double finish_in_wave(double* lds) {
+        static_assert(CW == 4 || CW == 32, "record widths of the two exchanges");
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < B; ++k) acc += v[k];
+        if (CW == 4) {
+            acc += dpp_move<0x114>(acc); // row_shr:4
+            acc += dpp_move<0x118>(acc); // row_shr:8: lanes 12..15 of every row of 16 hold the row's four groups
+            acc = halve_bit4(acc, acc);
+        }
+        acc = halve_bit5(acc, acc);
+        if (CW == 4) {
+            if (lane >= 12 && lane < 16) lds[wave * CW + (lane - 12)] = acc;
+        } else {
+            if (lane < CW) lds[wave * CW + lane] = acc;
+        }
+        __syncthreads();
+        double out = 0.0;
+        if (threadIdx.x < NV) {
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) out += lds[w * CW + threadIdx.x];
+        }
         return out;
     }
 };

@@ -137,7 +137,7 @@ __device__ __forceinline__ bool grid_total(double mine, double& out, const GridE
                 f.v[k] = __hip_atomic_load(cur + (size_t)(grp + k * GR) * RW + col, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    out = f.finish(cur, 0, RW, lds); // rows = 0: everything is already in f.v; synchronises the workgroup
+    out = f.finish_in_wave(lds); // synchronises the workgroup once
     // Every workgroup has published into `cur`, hence has finished reading `old`: reset this
     // workgroup's record there; that slot is next used two exchanges from now.
     if (threadIdx.x < RW)
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
                                                           GridExchange gx, double* __restrict__ hist, int hist_rows,
                                                           double* __restrict__ host_state) {
     __shared__ double st[PICP_STATE_DOUBLES];
-    __shared__ double lds[NTR];
+    __shared__ double lds[NTR];      // workgroup sums
+    __shared__ double lds_fold[NTR]; // folds of the exchanged records (a second buffer spares barriers)
     __shared__ double s1[PICP_S1_DOUBLES];
     __shared__ double s2[PICP_S2_DOUBLES];
     __shared__ double row[PICP_HIST_STRIDE];
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
             }
         {
             const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
-            const double tot = block_sum<3, NTR>(vals, lds);
-            double g = 0.0;
-            if (!grid_total<3, 2>(tot, g, gx, epoch, lds, &flag)) return;
+            const double tot = block_sum<3, NTR, false>(vals, lds);
+            double g = tot;
+            if (gridDim.x > 1 && !grid_total<3, 2>(tot, g, gx, epoch, lds_fold, &flag)) return;
             if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < 3) ? g : 0.0;
             __syncthreads();
         }
@@ -289,9 +290,9 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
                 }
             double vals[S2_USED];
             pack_sets(s, vals);
-            const double tot = block_sum<S2_USED, NTR>(vals, lds);
+            const double tot = block_sum<S2_USED, NTR, false>(vals, lds);
             double g = 0.0;
-            if (!grid_total<S2_USED, 16>(tot, g, gx, epoch, lds, &flag)) return;
+            if (!grid_total<S2_USED, 16>(tot, g, gx, epoch, lds_fold, &flag)) return;
             if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = (threadIdx.x < S2_USED) ? g : 0.0;
             __syncthreads();
         } else {
