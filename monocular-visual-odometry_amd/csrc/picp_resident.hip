@@ -488,7 +488,10 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     // workgroups than that R needs
     const int64_t lanes = (int64_t)resident_grid(ctx) * NTR;
     const int64_t per_thread = (M + lanes - 1) / lanes;
-    const int R = per_thread <= 1 ? 1 : (per_thread <= 2 ? 2 : (per_thread <= 4 ? 4 : (per_thread <= 8 ? 8 : 16)));
+    static const int steps[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    int R = 16;
+    for (int k = 7; k >= 0; --k)
+        if (steps[k] >= per_thread) R = steps[k];
     const int grid = (int)((M + (int64_t)NTR * R - 1) / ((int64_t)NTR * R));
     PICP_REQUIRE(grid >= 1 && grid <= resident_grid(ctx), "resident loop: grid %d does not fit %d CUs", grid,
                  resident_grid(ctx));
@@ -498,13 +501,21 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     memcpy(pose.m, w_T_c0_host, sizeof(pose.m));
     hipLaunchKernelGGL(resident_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->rslots, n, state,
                        pose, sched->kernel_threshold, sched->damping, sched->num_iterations);
+#define PICP_RESIDENT_CASE(RR) \
+    case RR: launch_resident<RR>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
     switch (R) {
-    case 1: launch_resident<1>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
-    case 2: launch_resident<2>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
-    case 4: launch_resident<4>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
-    case 8: launch_resident<8>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
-    default: launch_resident<16>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
+        PICP_RESIDENT_CASE(1)
+        PICP_RESIDENT_CASE(2)
+        PICP_RESIDENT_CASE(3)
+        PICP_RESIDENT_CASE(4)
+        PICP_RESIDENT_CASE(6)
+        PICP_RESIDENT_CASE(8)
+        PICP_RESIDENT_CASE(12)
+    default:
+        launch_resident<16>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1);
+        break;
     }
+#undef PICP_RESIDENT_CASE
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
 }

@@ -313,10 +313,10 @@ def test_association_signed_zero_and_nan(ctx, assoc_mode):
     assert r1.tolist() == [0, 1, 3, 4] and r2.tolist() == [10, 11, 13, 10]
 
 
-@pytest.mark.parametrize("M", [1_500_001, 1 << 20, 300_001, 70_000])
+@pytest.mark.parametrize("M", [1 << 21, 1_500_001, 1 << 20, 700_001, 300_001, 70_000])
 def test_large_loop_against_oracle(ctx, loop_path, M):
-    """Up to 1.5 M correspondences, 6 iterations: counts exact, H/b/T within 1e-9 of the numpy oracle.
-    The sizes put 16, 8, 4 (ragged) and 1 correspondences per thread into the single-launch loop."""
+    """Up to 2^21 correspondences, 6 iterations: counts exact, H/b/T within 1e-9 of the numpy oracle.
+    The sizes put 16, 12, 8, 6, 3 (ragged) and 1 correspondences per thread into the single-launch loop."""
     if loop_path == "resident":
         assert M <= ctx.resident_capacity()
     uv, pw, _ = make_problem(M, seed=0)
