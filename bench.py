@@ -163,12 +163,15 @@ def main():
     if os.environ.get("PICP_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    collective = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+            collective = "rccl"
         else:
             dist.init_process_group(backend)
+            collective = backend
     from tests.synthetic import true_pose
     pkg = importlib.import_module("monocular-visual-odometry_amd")
     L = pkg._lib
@@ -259,6 +262,7 @@ def main():
                                     f"{world} GPU(s), 20 LM iterations, 2 all-reduces per iteration"),
                        "correspondences": M, "lm_iterations": ITERATIONS,
                        "device_path": "single launch, register-resident" if resident else "streaming stage launches",
+                       "collective": collective,
                        "final_pose_error": float(np.max(np.abs(np.array(list(res.T)).reshape(4, 4) - true_pose())))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
