@@ -81,3 +81,69 @@ def test_two_ranks_sharing_the_gpu():
         assert n_inl == h_ref["num_inliers"] and n_in == h_ref["n_inside"]
         assert rel_err(T, T_ref) < 1e-9
     assert np.array_equal(results[0][1], results[1][1])
+
+
+def _device_problem(ctx, M, seed=0, chunk=1 << 23):
+    """The synthetic problem of tests/synthetic.make_problem generated on the device (torch), in
+    chunks, as five SoA planes; returns (planes [5][M], true pose)."""
+    from tests.synthetic import true_pose
+    T = true_pose()
+    c_T_w = torch.tensor(np.linalg.inv(T), dtype=torch.float64, device=ctx.device)
+    planes = ctx.zeros((5, L._pad32(M)))
+    gen = torch.Generator(device=ctx.device)
+    gen.manual_seed(seed)
+    for lo in range(0, M, chunk):
+        n = min(chunk, M - lo)
+        r = torch.rand((6, n), dtype=torch.float64, device=ctx.device, generator=gen)
+        z = 1.0 + 19.0 * r[0]
+        px, py = 640.0 * r[1], 480.0 * r[2]
+        pw = torch.stack([(px - 320.0) / 180.0 * z, (py - 240.0) / 180.0 * z, z])
+        pc = c_T_w[:3, :3] @ pw + c_T_w[:3, 3:4]
+        u = 180.0 * pc[0] / pc[2] + 320.0 + 0.5 * torch.randn(n, dtype=torch.float64, device=ctx.device, generator=gen)
+        v = 180.0 * pc[1] / pc[2] + 240.0 + 0.5 * torch.randn(n, dtype=torch.float64, device=ctx.device, generator=gen)
+        outlier = r[3] < 0.1
+        u = torch.where(outlier, 640.0 * r[4], u)
+        v = torch.where(outlier, 480.0 * r[5], v)
+        planes[0, lo:lo + n], planes[1, lo:lo + n] = u, v
+        planes[2:5, lo:lo + n] = pw
+    return [planes[k][:M] for k in range(5)], T
+
+
+def test_64M_correspondences_in_eight_shards_equal_one_array():
+    """The sharded configuration at its full size (2^26 correspondences, 8 shards), with the eight
+    shards processed one after the other on the one GPU and their records added where the ranks of a
+    node would all-reduce them: in-image and inlier counts identical to the loop over the whole
+    array, poses within 1e-9, the eight replicated states bit-identical, and the loop converges to the
+    true pose."""
+    ctx = pkg.get_context(0)
+    M, world, n_it = 1 << 26, 8, 8
+    corr, T_true = _device_problem(ctx, M)
+    cam, sched = _cam_sched(n_it, True)
+    res, hist = ctx.run(corr, np.eye(4), cam, sched)             # streaming path (beyond the on-chip capacity)
+    assert res.num_iterations == n_it
+    shards = []
+    for r in range(world):
+        lo, hi = pkg.sharded.shard_bounds(M, r, world)
+        shards.append(pkg.sharded.HipStages(ctx, [c[lo:hi] for c in corr], np.eye(4), cam, sched))
+    for s in shards:
+        s.state_init()
+    for _ in range(n_it):
+        s1 = torch.zeros(L.S1_DOUBLES, dtype=torch.float64, device=ctx.device)
+        for s in shards:
+            s1 += s.stage1()
+        s2 = torch.zeros(L.S2_DOUBLES, dtype=torch.float64, device=ctx.device)
+        for s in shards:
+            s2 += s.stage2(s1)
+        for s in shards:
+            s.solve(s1, s2)
+    outs = [s.finish() for s in shards]
+    states = [s.state.cpu().numpy() for s in shards]
+    for st in states[1:]:
+        assert np.array_equal(st, states[0])
+    res8, hist8 = outs[0]
+    assert res8.num_iterations == n_it
+    for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_KERNEL_THR, L.H_DAMPING):
+        assert np.array_equal(hist8[:, col], hist[:, col]), col
+    assert int(hist[0, L.H_N_INSIDE]) > 0.9 * M
+    assert rel_err(hist8[:, L.H_T:L.H_T + 16], hist[:, L.H_T:L.H_T + 16]) < 1e-9
+    assert np.max(np.abs(np.array(list(res8.T)).reshape(4, 4) - T_true)) < 1e-3
