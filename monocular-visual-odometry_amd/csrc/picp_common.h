@@ -37,6 +37,8 @@ struct picp_ctx {
     int64_t resident_limit;        // largest M the resident loop is used for (0: never)
     unsigned resident_spin_limit;  // polls before a waiting workgroup abandons the launch
     int resident_aborts;           // launches abandoned so far (each was repeated with the streaming kernels)
+    int resident_clean_grid;       // exchange slots hold sentinels for launches of up to this many workgroups
+    int resident_last_grid;        // workgroups of the last launch
 };
 
 namespace picp {
@@ -56,6 +58,7 @@ int hip_fail(hipError_t e, const char* what);
 
 // picp_resident.hip
 int64_t resident_capacity(const picp_ctx* ctx);
+void resident_refill(picp_ctx* ctx);
 int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
                      const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,

@@ -101,6 +101,7 @@ int picp_destroy(picp_ctx* ctx) {
 int picp_set_stream(picp_ctx* ctx, void* stream) {
     PICP_REQUIRE(ctx != nullptr, "picp_set_stream: null ctx");
     ctx->stream = static_cast<hipStream_t>(stream);
+    ctx->resident_clean_grid = 0; // slot refills enqueued on the old stream are not ordered with the new one
     return PICP_OK;
 }
 

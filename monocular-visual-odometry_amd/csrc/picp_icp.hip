@@ -572,6 +572,7 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
         PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // the kernel left the final state in ctx->pinned
         if (ctx->pinned[ST_STOP] != 0.0) {
             result_from_state(ctx->pinned, w_T_c0_host, result);
+            resident_refill(ctx);
             return PICP_OK;
         }
         // the launch was abandoned at a grid-wide wait (device shared with other work): start over

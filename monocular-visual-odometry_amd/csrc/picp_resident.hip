@@ -71,13 +71,12 @@ struct StartPose {
     double m[16];
 };
 
-// First launch step: every record of every slot holds the sentinel, and the state block holds the
-// loop entry state (src/ProjectiveICP.py:157-171).
-__global__ void resident_prepare_kernel(double* slots, int n, double* state, StartPose pose, double thr, double lambda,
-                                        int num_iterations) {
+// Every record of every slot holds the sentinel.  Run before a launch whose slots are not known to
+// be clean, and again (asynchronously) after a completed loop, so that the next loop of the same
+// shape starts without waiting for it.
+__global__ void resident_fill_kernel(double* slots, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) slots[i] = __longlong_as_double((long long)SENTINEL_BITS);
-    if (i == 0) init_state(state, pose.m, thr, lambda, num_iterations);
 }
 
 // Grid-wide sum of NV values.  `mine`: this workgroup's total of value tid (threads tid < NV).
@@ -198,9 +197,9 @@ template <int R, bool PINHOLE>
 __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                           const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, int64_t M,
-                                                          double* __restrict__ state, CameraK cam, picp_schedule sc,
-                                                          GridExchange gx, double* __restrict__ hist, int hist_rows,
-                                                          double* __restrict__ host_state) {
+                                                          double* __restrict__ state, StartPose pose0, CameraK cam,
+                                                          picp_schedule sc, GridExchange gx, double* __restrict__ hist,
+                                                          int hist_rows, double* __restrict__ host_state) {
     __shared__ double st[PICP_STATE_DOUBLES];
     __shared__ double lds[NTR];      // workgroup sums
     __shared__ double lds_fold[NTR]; // folds of the exchanged records (a second buffer spares barriers)
@@ -235,8 +234,11 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         rz[r] = z[j];
         mine += ok ? 1 : 0;
     }
-    if (threadIdx.x < PICP_STATE_DOUBLES) st[threadIdx.x] = state[threadIdx.x];
-    if (threadIdx.x == 0) flag = 0;
+    // loop entry (src/ProjectiveICP.py:157-171): every workgroup builds its own copy of the state
+    if (threadIdx.x == 0) {
+        init_state(st, pose0.m, sc.kernel_threshold, sc.damping, sc.num_iterations);
+        flag = 0;
+    }
     __syncthreads();
 
     unsigned epoch = 0;
@@ -450,7 +452,7 @@ int64_t resident_capacity(const picp_ctx* ctx) {
 
 template <int R>
 static void launch_resident(picp_ctx* ctx, int grid, const double* u, const double* v, const double* x, const double* y,
-                            const double* z, int64_t M, double* state, const picp_camera* cam,
+                            const double* z, int64_t M, double* state, const StartPose& pose, const picp_camera* cam,
                             const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
                             hipEvent_t e1) {
     const CameraK c = camera_of(cam);
@@ -467,14 +469,31 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
         }
     }
     if (e0 != nullptr)
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, c, *sched,
-                              gx, hist, hist_rows, host_state);
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, pose, c,
+                              *sched, gx, hist, hist_rows, host_state);
     else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, u, v, x, y, z, M, state, c, *sched, gx,
-                           hist, hist_rows, host_state);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, u, v, x, y, z, M, state, pose, c, *sched,
+                           gx, hist, hist_rows, host_state);
 }
 
-// Enqueues loop entry (state block from w_T_c0_host) and the loop.  Precondition:
+static void fill_slots(picp_ctx* ctx, int grid) {
+    const int n = SLOTS * grid * RW;
+    hipLaunchKernelGGL(resident_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->rslots, n);
+}
+
+// After a loop has been waited for: restore the exchange slots for the next loop of up to the same
+// number of workgroups.  Only enqueued, so it overlaps whatever the host does next; work the caller
+// puts on the stream later is ordered behind it.
+void resident_refill(picp_ctx* ctx) {
+    if (ctx->resident_last_grid > 1) {
+        fill_slots(ctx, ctx->resident_last_grid);
+        ctx->resident_clean_grid = ctx->resident_last_grid;
+    } else {
+        ctx->resident_clean_grid = 1; // a single workgroup exchanges nothing
+    }
+}
+
+// Enqueues the loop, starting from w_T_c0_host.  Precondition:
 // 0 < M <= resident_capacity(ctx).  A launch that gave up at a grid-wide wait leaves the state's
 // stop flag clear (the final state is only written by a loop that ran to its end).  host_state:
 // optional host-visible (pinned) block that also receives the final state, cleared here first.
@@ -495,14 +514,14 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     const int grid = (int)((M + (int64_t)NTR * R - 1) / ((int64_t)NTR * R));
     PICP_REQUIRE(grid >= 1 && grid <= resident_grid(ctx), "resident loop: grid %d does not fit %d CUs", grid,
                  resident_grid(ctx));
-    const int n = SLOTS * grid * RW;
     if (host_state != nullptr) host_state[ST_STOP] = 0.0;
     StartPose pose;
     memcpy(pose.m, w_T_c0_host, sizeof(pose.m));
-    hipLaunchKernelGGL(resident_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->rslots, n, state,
-                       pose, sched->kernel_threshold, sched->damping, sched->num_iterations);
+    if (ctx->resident_clean_grid < grid) fill_slots(ctx, grid); // else a previous call left them clean
+    ctx->resident_clean_grid = 0;                               // the loop dirties them
+    ctx->resident_last_grid = grid;
 #define PICP_RESIDENT_CASE(RR) \
-    case RR: launch_resident<RR>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1); break;
+    case RR: launch_resident<RR>(ctx, grid, u, v, x, y, z, M, state, pose, cam, sched, hist, hist_rows, host_state, e0, e1); break;
     switch (R) {
         PICP_RESIDENT_CASE(1)
         PICP_RESIDENT_CASE(2)
@@ -512,7 +531,7 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
         PICP_RESIDENT_CASE(8)
         PICP_RESIDENT_CASE(12)
     default:
-        launch_resident<16>(ctx, grid, u, v, x, y, z, M, state, cam, sched, hist, hist_rows, host_state, e0, e1);
+        launch_resident<16>(ctx, grid, u, v, x, y, z, M, state, pose, cam, sched, hist, hist_rows, host_state, e0, e1);
         break;
     }
 #undef PICP_RESIDENT_CASE
