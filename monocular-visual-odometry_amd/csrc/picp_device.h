@@ -577,39 +577,46 @@ __device__ inline void v2T_device(const double* v, double* T) {
     numpy_sincosf((float)v[4], &fsy, &fcy);
     numpy_sincosf((float)v[5], &fsz, &fcz);
     const double cx = fcx, sx = fsx, cy = fcy, sy = fsy, cz = fcz, sz = fsz;
-    const double Rx[9] = {1.0, 0.0, 0.0, 0.0, cx, -sx, 0.0, sx, cx};
-    const double Ry[9] = {cy, 0.0, sy, 0.0, 1.0, 0.0, -sy, 0.0, cy};
-    const double Rz[9] = {cz, -sz, 0.0, sz, cz, 0.0, 0.0, 0.0, 1.0};
-    double Rxy[9], R[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            Rxy[i * 3 + j] = Rx[i * 3 + 0] * Ry[0 * 3 + j] + Rx[i * 3 + 1] * Ry[1 * 3 + j] + Rx[i * 3 + 2] * Ry[2 * 3 + j];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            R[i * 3 + j] = Rxy[i * 3 + 0] * Rz[0 * 3 + j] + Rxy[i * 3 + 1] * Rz[1 * 3 + j] + Rxy[i * 3 + 2] * Rz[2 * 3 + j];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
-        T[i * 4 + 3] = v[i];
-    }
+    // R = (Rx Ry) Rz written out.  The factors hold exact zeros and ones, so in the reference's
+    // two 3x3 products every entry of Rx Ry is a single product and every entry of R a sum of at
+    // most two products; the terms multiplied by zero or one are left out (they do not change a
+    // floating-point sum).
+    const double a00 = cy, a02 = sy;                       // Rx Ry, row 0 (a01 = 0)
+    const double a10 = sx * sy, a11 = cx, a12 = -(sx * cy); // row 1
+    const double a20 = -(cx * sy), a21 = sx, a22 = cx * cy; // row 2
+    T[0] = a00 * cz;
+    T[1] = -(a00 * sz);
+    T[2] = a02;
+    T[4] = a10 * cz + a11 * sz;
+    T[5] = a11 * cz - a10 * sz;
+    T[6] = a12;
+    T[8] = a20 * cz + a21 * sz;
+    T[9] = a21 * cz - a20 * sz;
+    T[10] = a22;
+    T[3] = v[0];
+    T[7] = v[1];
+    T[11] = v[2];
     T[12] = 0.0;
     T[13] = 0.0;
     T[14] = 0.0;
     T[15] = 1.0;
 }
 
+// C = A B for two pose matrices (last rows (0, 0, 0, 1), which every pose here has: the state is
+// checked on entry and v2T builds the increment): the products with that row are exact, so only the
+// twelve entries of the upper three rows are formed.
 __device__ inline void matmul4(const double* A, const double* B, double* C) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            C[i * 4 + j] = A[i * 4 + 0] * B[0 * 4 + j] + A[i * 4 + 1] * B[1 * 4 + j] + A[i * 4 + 2] * B[2 * 4 + j] +
-                           A[i * 4 + 3] * B[3 * 4 + j];
+        for (int j = 0; j < 3; ++j)
+            C[i * 4 + j] = A[i * 4 + 0] * B[0 * 4 + j] + A[i * 4 + 1] * B[1 * 4 + j] + A[i * 4 + 2] * B[2 * 4 + j];
+        C[i * 4 + 3] = A[i * 4 + 0] * B[0 * 4 + 3] + A[i * 4 + 1] * B[1 * 4 + 3] + A[i * 4 + 2] * B[2 * 4 + 3] + A[i * 4 + 3];
+    }
+    C[12] = 0.0;
+    C[13] = 0.0;
+    C[14] = 0.0;
+    C[15] = 1.0;
 }
 
 // np.add.reduce over 10 contiguous doubles: numpy's pairwise summation keeps 8 running sums for
