@@ -111,15 +111,17 @@ int picp_synchronize(picp_ctx* ctx);
  * linearise (:276-353), damped solve + pose update (:260-273), schedules (:200-228).
  * hist: device, [hist_rows][PICP_HIST_STRIDE], hist_rows >= num_iterations.
  * state: device, PICP_STATE_DOUBLES doubles of scratch owned by the caller.
- * Synchronises the stream before returning; result is host memory. */
+ * Synchronises the stream before returning; result is host memory.  (After the synchronisation a
+ * sub-microsecond housekeeping kernel may be left enqueued on the stream; later work is ordered
+ * behind it.) */
 int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
              int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched,
              double* state, double* hist, int32_t hist_rows, picp_result* result);
 
 /* picp_run has two device paths with the same results (sums differ only in the order of additions):
  * up to picp_resident_capacity(ctx) correspondences the whole loop is ONE launch that reads the five
- * arrays once and keeps them in registers, exchanging the two per-iteration sums of :301 and :313-317
- * between workgroups inside the kernel; larger inputs stream the arrays twice per iteration through
+ * arrays once and keeps them in registers and LDS, exchanging the two per-iteration sums of :301 and
+ * :313-317 between workgroups inside the kernel; larger inputs stream the arrays twice per iteration through
  * separate launches.  picp_set_resident_limit lowers the switch point (0 = always stream); the
  * capacity is a property of the device (CUs x threads x registers). */
 int picp_set_resident_limit(picp_ctx* ctx, int64_t max_correspondences);
