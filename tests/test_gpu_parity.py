@@ -372,8 +372,8 @@ def test_projective_icp_class_on_bundled_frames(ctx, bundled, tmp_path, monkeypa
 def test_single_launch_loop_gives_up_cleanly(monkeypatch):
     """With a wait bound of zero polls the single-launch loop abandons its launch as soon as one record
     is not there at first look; picp_run must then repeat the loop with the streaming kernels and
-    return the same result.  (Whether a given launch gives up depends on timing; over several runs
-    with 137 workgroups and 12 exchanges each, some do.)"""
+    return the same result.  (Whether a given launch gives up depends on timing; with 137 workgroups and
+    12 exchanges per run most runs do.)"""
     monkeypatch.setenv("PICP_RESIDENT_SPIN_LIMIT", "0")
     impatient = L.Context(0)
     monkeypatch.delenv("PICP_RESIDENT_SPIN_LIMIT")
@@ -381,11 +381,13 @@ def test_single_launch_loop_gives_up_cleanly(monkeypatch):
     uv, pw, _ = make_problem(M, seed=3)
     T_ref, _, h_ref = po.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=6, disable_stop=True))
     corr = impatient.soa(uv, pw)
-    for _ in range(5):
+    for _ in range(60):         # until a launch has given up (normally the first or second)
         res, hist = impatient.run(corr, np.eye(4), bundled_cam(), yaml_sched(6, disable_stop=True))
         assert res.num_iterations == 6
         assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h_ref["num_inliers"]))
         assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
+        if impatient.resident_aborts() >= 3:
+            break
     assert impatient.resident_aborts() >= 1
 
 
