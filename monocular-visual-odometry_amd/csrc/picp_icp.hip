@@ -224,9 +224,9 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
 }
 
 // ---- whole loop in one workgroup, one problem per workgroup -------------------------------------
-// R > 0: each thread keeps up to R correspondences in registers for the whole loop, so the data
-// is read from HBM once per problem.  R == 0: any size, re-read (from cache) every iteration.
-template <int R, bool PINHOLE>
+// Problems of any size: the correspondences are re-read (from cache) every iteration.  Problems
+// with a known bound on their size are held on chip instead (picp_resident.hip).
+template <bool PINHOLE>
 __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                          const double* __restrict__ x, const double* __restrict__ y,
                                                          const double* __restrict__ z,
@@ -243,20 +243,6 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
     const int64_t beg = offsets[prob];
     const int cnt = (int)(offsets[prob + 1] - beg);
     if (threadIdx.x == 0) init_state(st, poses0 + (size_t)prob * 16, sc.kernel_threshold, sc.damping, sc.num_iterations);
-    constexpr int RR = (R > 0) ? R : 1;
-    double ru[RR], rv[RR], rx[RR], ry[RR], rz[RR];
-    if (R > 0) {
-#pragma unroll
-        for (int r = 0; r < RR; ++r) {
-            const int i = r * NT + threadIdx.x;
-            const bool ok = i < cnt;
-            ru[r] = ok ? u[beg + i] : 0.0;
-            rv[r] = ok ? v[beg + i] : 0.0;
-            rx[r] = ok ? x[beg + i] : 0.0;
-            ry[r] = ok ? y[beg + i] : 0.0;
-            rz[r] = ok ? z[beg + i] : 0.0;
-        }
-    }
     __syncthreads();
     double* myhist = (hist != nullptr) ? hist + (size_t)prob * hist_rows * PICP_HIST_STRIDE : nullptr;
     while (st[ST_STOP] == 0.0) {
@@ -265,15 +251,8 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
         for (int i = 0; i < 12; ++i) T[i] = st[ST_C_T_W + i];
         const double thr = st[ST_THR];
         Stage1Sums a{0.0, 0u, 0u};
-        if (R > 0) {
-#pragma unroll
-            for (int r = 0; r < RR; ++r)
-                if (r * NT + (int)threadIdx.x < cnt)
-                    stage1_point<PINHOLE>(T, cam, thr, ru[r], rv[r], rx[r], ry[r], rz[r], a);
-        } else {
-            for (int i = threadIdx.x; i < cnt; i += NT)
-                stage1_point<PINHOLE>(T, cam, thr, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], a);
-        }
+        for (int i = threadIdx.x; i < cnt; i += NT)
+            stage1_point<PINHOLE>(T, cam, thr, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], a);
         {
             const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
             const double tot = block_sum<3, NT>(vals, lds);
@@ -289,16 +268,9 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
                 const bool all = (st[ST_MODE] != 0.0);
                 Stage2Sums s;
                 s.clear();
-                if (R > 0) {
-#pragma unroll
-                    for (int r = 0; r < RR; ++r)
-                        if (r * NT + (int)threadIdx.x < cnt)
-                            stage2_point<PINHOLE>(T, cam, thr, mean, all, ru[r], rv[r], rx[r], ry[r], rz[r], s);
-                } else {
-                    for (int i = threadIdx.x; i < cnt; i += NT)
-                        stage2_point<PINHOLE>(T, cam, thr, mean, all, u[beg + i], v[beg + i], x[beg + i], y[beg + i],
-                                              z[beg + i], s);
-                }
+                for (int i = threadIdx.x; i < cnt; i += NT)
+                    stage2_point<PINHOLE>(T, cam, thr, mean, all, u[beg + i], v[beg + i], x[beg + i], y[beg + i],
+                                          z[beg + i], s);
                 double vals[S2_USED];
                 pack_sets(s, vals);
                 const double tot = block_sum<S2_USED, NT>(vals, lds);
@@ -623,7 +595,7 @@ int picp_run_batched(picp_ctx* ctx, const double* u, const double* v, const doub
         return enqueue_batched_resident(ctx, B, max_count, u, v, x, y, z, offsets, poses0, cam, sched, results, hist,
                                         (int)hist_rows);
     const CameraK c = to_device_camera(cam);
-    auto kern = is_pinhole(cam->K) ? icp_batched_kernel<0, true> : icp_batched_kernel<0, false>;
+    auto kern = is_pinhole(cam->K) ? icp_batched_kernel<true> : icp_batched_kernel<false>;
     hipLaunchKernelGGL(kern, dim3(B), dim3(NT), 0, ctx->stream, u, v, x, y, z, offsets, poses0, c, *sched, results,
                        hist, (int)hist_rows);
     PICP_HIP_CHECK(hipGetLastError());
