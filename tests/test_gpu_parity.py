@@ -451,3 +451,35 @@ def test_random_problems_against_oracle(ctx, loop_path):
             check_best(np.array(list(res.T)).reshape(4, 4), res.best_index, np.array(h["error"]), np.array(h["T"]), T_ref)
         else:
             assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL, k
+
+
+def test_plain_c_host_program_on_the_c_abi(ctx, tmp_path):
+    """examples/picp_host_demo.c -- gcc, hipMalloc, raw device pointers, no Python in the process --
+    gives the same loop as the ctypes path and the oracle."""
+    import os
+    import struct
+    import subprocess
+    from tests.helpers import ROOT
+    exe = os.path.join(ROOT, "examples", "picp_host_demo")
+    if not os.path.exists(exe):
+        pytest.skip("examples/picp_host_demo is not built (`make -C examples`; build() does it)")
+    M, n_it = 20_001, 40
+    uv, pw, _ = make_problem(M, seed=17)
+    pose = po.v2T([0.02, -0.01, 0.05, 0.004, -0.003, 0.002])
+    with open(tmp_path / "in.bin", "wb") as fh:
+        fh.write(struct.pack("<qq", M, n_it))
+        fh.write(np.ascontiguousarray(pose, dtype=np.float64).tobytes())
+        fh.write(np.ascontiguousarray(np.concatenate([uv.T, pw.T]), dtype=np.float64).tobytes())
+    done = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True,
+                          timeout=120)
+    assert done.returncode == 0, done.stderr
+    raw = open(tmp_path / "out.bin", "rb").read()
+    T = np.frombuffer(raw[:128], dtype=np.float64).reshape(4, 4)
+    valid, n_run, best, _ = struct.unpack("<iiii", raw[128:144])
+    hist = np.frombuffer(raw[152:], dtype=np.float64).reshape(n_run, L.HIST_STRIDE)
+    T_ref, valid_ref, h = po.projective_icp(uv, pw, pose, po.IcpParams(num_iterations=n_it), record_linear=True)
+    assert n_run == len(h["error"]) and bool(valid) == valid_ref
+    assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h["num_inliers"]))
+    assert np.array_equal(hist[:, L.H_N_INSIDE].astype(np.int64), np.array(h["n_inside"]))
+    assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(h["T"])) < TOL
+    check_best(T, best, np.array(h["error"]), np.array(h["T"]), T_ref)
