@@ -55,3 +55,20 @@ def test_product_path_fails_loudly_without_gpu():
     with pytest.raises(pkg.PicpError):
         pkg.data_association_on_appearance({"position": [[0, 0]], "appearance": [[1.0]]},
                                            {"position": [[0, 0, 1]], "appearance": [[1.0]]})
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    """include/picp_hip.h is the boundary other host languages bind: it must be valid C99 on its own."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "picp_hip.h"\nint main(void) { picp_result r; picp_schedule s; picp_camera c;\n'
+                   '  (void)r; (void)s; (void)c; return sizeof(picp_result) == 152 ? 0 : 1; }\n')
+    header_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    done = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", header_dir, str(src)],
+                          capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr
