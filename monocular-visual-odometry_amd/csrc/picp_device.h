@@ -442,6 +442,18 @@ struct PartialFold {
     }
 };
 
+// finish() with one barrier when every row was covered by issue() (rows <= B * G), else the general form.
+template <int NV, int NT, int B>
+__device__ __forceinline__ double finish_fold(PartialFold<NV, NT, B>& f, const double* __restrict__ part, int rows,
+                                              int stride, double* lds) {
+    if (rows <= B * PartialFold<NV, NT, B>::G) { // uniform over the workgroup
+        const double out = f.finish_in_wave(lds);
+        __syncthreads(); // lds may be written again right away by the caller
+        return out;
+    }
+    return f.finish(part, rows, stride, lds);
+}
+
 template <int NV, int NT, int B = 16>
 __device__ __forceinline__ double fold_partials(const double* __restrict__ part, int rows, int stride, double* lds) {
     PartialFold<NV, NT, B> f;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NT2) void stage2_kernel(const double* __restrict__ 
     f1.issue(s1part, s1rows, PICP_S1_DOUBLES);
     if (state[ST_STOP] != 0.0) return;
     {
-        const double tot = f1.finish(s1part, s1rows, PICP_S1_DOUBLES, lds);
+        const double tot = finish_fold(f1, s1part, s1rows, PICP_S1_DOUBLES, lds);
         if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = tot;
         __syncthreads();
     }
@@ -208,9 +208,9 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
     __syncthreads();
     if (st[ST_STOP] != 0.0) return;
     {
-        const double t1 = f1.finish(s1part, s1rows, PICP_S1_DOUBLES, lds);
+        const double t1 = finish_fold(f1, s1part, s1rows, PICP_S1_DOUBLES, lds);
         if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = t1;
-        const double t2 = f2.finish(s2part, s2rows, PICP_S2_DOUBLES, lds);
+        const double t2 = finish_fold(f2, s2part, s2rows, PICP_S2_DOUBLES, lds);
         if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = t2;
         __syncthreads();
     }
