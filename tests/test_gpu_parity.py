@@ -483,3 +483,19 @@ def test_plain_c_host_program_on_the_c_abi(ctx, tmp_path):
     assert np.array_equal(hist[:, L.H_N_INSIDE].astype(np.int64), np.array(h["n_inside"]))
     assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(h["T"])) < TOL
     check_best(T, best, np.array(h["error"]), np.array(h["T"]), T_ref)
+
+
+def test_large_loop_against_the_c_restatement(ctx, loop_path):
+    """2^20 correspondences, 8 iterations, against the C restatement that works one correspondence at a
+    time in the reference's order (numpy's pairwise means included): counts exact, poses within 1e-9."""
+    from oracle import picp_oracle_c as oc
+    M = 1 << 20
+    uv, pw, _ = make_problem(M, seed=21)
+    T_ref, valid_ref, rows, best = oc.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=8, disable_stop=True))
+    res, hist = ctx.run(ctx.soa(uv, pw), np.eye(4), bundled_cam(), yaml_sched(8, disable_stop=True))
+    assert res.num_iterations == 8 and bool(res.valid) == valid_ref
+    for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_KERNEL_THR, L.H_DAMPING, L.H_N_STAGE1, L.H_N_STAGE2, L.H_USED_STAGE2):
+        assert np.array_equal(hist[:, col], rows[:, col]), col
+    assert rel_err(hist[:, L.H_T:L.H_T + 16], rows[:, L.H_T:L.H_T + 16]) < TOL
+    for k in range(8):
+        assert rel_err(hist[k, L.H_H:L.H_H + 36], rows[k, L.H_H:L.H_H + 36]) < TOL
