@@ -29,82 +29,6 @@ __global__ void state_init_kernel(double* st, Pose16 pose, double thr, double la
 }
 
 // ---- stage 1 --------------------------------------------------------------------------------
-// Five 16-byte loads = two correspondences per lane.
-struct Corr2 {
-    double2 u, v, x, y, z;
-};
-__device__ __forceinline__ Corr2 load2(const double2* __restrict__ u, const double2* __restrict__ v,
-                                       const double2* __restrict__ x, const double2* __restrict__ y,
-                                       const double2* __restrict__ z, int64_t i) {
-    Corr2 c;
-    c.u = u[i];
-    c.v = v[i];
-    c.x = x[i];
-    c.y = y[i];
-    c.z = z[i];
-    return c;
-}
-
-// Streams a workgroup grid's share of the correspondences through `point(mu, mv, x, y, z)`.
-// VEC == 2: 16-byte loads; the loads of the next grid-stride step are issued before the current
-// pair of correspondences is processed, so a wave always has a full step of HBM requests in flight
-// while it computes.  start() issues the very first loads; kernels call it before their prologue
-// (state, partial records), because the addresses depend on nothing but the thread index.
-template <int VEC, int THREADS>
-struct CorrStream {
-    const double *u, *v, *x, *y, *z;
-    int64_t M, stride, tid;
-    Corr2 A;
-    __device__ __forceinline__ void start(const double* u_, const double* v_, const double* x_, const double* y_,
-                                          const double* z_, int64_t M_) {
-        u = u_, v = v_, x = x_, y = y_, z = z_, M = M_;
-        stride = (int64_t)gridDim.x * THREADS;
-        tid = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-        if (VEC == 2 && tid < (M >> 1))
-            A = load2(reinterpret_cast<const double2*>(u), reinterpret_cast<const double2*>(v),
-                      reinterpret_cast<const double2*>(x), reinterpret_cast<const double2*>(y),
-                      reinterpret_cast<const double2*>(z), tid);
-    }
-    template <typename F>
-    __device__ __forceinline__ void run(F&& point) {
-        if (VEC == 2) {
-            const int64_t n2 = M >> 1;
-            const double2* u2 = reinterpret_cast<const double2*>(u);
-            const double2* v2 = reinterpret_cast<const double2*>(v);
-            const double2* x2 = reinterpret_cast<const double2*>(x);
-            const double2* y2 = reinterpret_cast<const double2*>(y);
-            const double2* z2 = reinterpret_cast<const double2*>(z);
-            // Two register sets in ping-pong: while set A is processed the loads of set B are in
-            // flight and vice versa, with no register copies between steps.  The prefetch is
-            // unconditional (past the end it re-reads the current step, a cache hit whose data is
-            // dropped): a load under a lane-dependent branch would make the compiler wait for every
-            // outstanding load at the join, the prefetched ones included.
-            int64_t i = tid;
-            if (i < n2) {
-                Corr2 B;
-                for (;;) {
-                    const int64_t j = i + stride;
-                    const bool hasB = j < n2;
-                    B = load2(u2, v2, x2, y2, z2, hasB ? j : i);
-                    point(A.u.x, A.v.x, A.x.x, A.y.x, A.z.x);
-                    point(A.u.y, A.v.y, A.x.y, A.y.y, A.z.y);
-                    if (!hasB) break;
-                    const int64_t k = j + stride;
-                    const bool hasA = k < n2;
-                    A = load2(u2, v2, x2, y2, z2, hasA ? k : j);
-                    point(B.u.x, B.v.x, B.x.x, B.y.x, B.z.x);
-                    point(B.u.y, B.v.y, B.x.y, B.y.y, B.z.y);
-                    if (!hasA) break;
-                    i = k;
-                }
-            }
-            if ((M & 1) && tid == 0) point(u[M - 1], v[M - 1], x[M - 1], y[M - 1], z[M - 1]);
-        } else {
-            for (int64_t i = tid; i < M; i += stride) point(u[i], v[i], x[i], y[i], z[i]);
-        }
-    }
-};
-
 template <int VEC, bool PINHOLE>
 __global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                     const double* __restrict__ x, const double* __restrict__ y,
