@@ -171,6 +171,12 @@ int picp_stage1_reduce(picp_ctx* ctx, double* s1);
 int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                 const double* z, int64_t M, const double* state, const picp_camera* cam, const double* s1);
 int picp_stage2_reduce(picp_ctx* ctx, double* s2);
+/* Direction in which picp_stage2 walks the arrays: 0 = as picp_stage1 does, 1 = against it (stage 2
+ * then starts with what stage 1 read last, and the next stage 1 with what stage 2 read last, so
+ * arrays up to about twice the 256 MB memory-side cache are partly served from it), -1 = chosen by
+ * size (the default).  The sums are the same up to the order of additions.  No counterpart in the
+ * reference, whose loop visits the pairs in index order (src/ProjectiveICP.py:286). */
+int picp_set_stage2_order(picp_ctx* ctx, int32_t order);
 int picp_solve(picp_ctx* ctx, double* state, const picp_schedule* sched, const double* s1, const double* s2,
                double* hist, int32_t hist_rows);
 /* Timing aid for benchmarks: launches the stage-2 scan `reps` times, each dispatch bracketed by HIP

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "picp_stage1_reduce": (C.c_int, [_P, _P]),
     "picp_stage2": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), _P]),
     "picp_stage2_reduce": (C.c_int, [_P, _P]),
+    "picp_set_stage2_order": (C.c_int, [_P, C.c_int32]),
     "picp_profile_stage2": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_int32,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "picp_solve": (C.c_int, [_P, _P, C.POINTER(ScheduleStruct), _P, _P, _P, C.c_int32]),
@@ -232,6 +233,12 @@ class Context:
         (None: whatever fits the device; 0: always the streaming kernels)."""
         n = (1 << 62) if max_correspondences is None else int(max_correspondences)
         check(self.lib.picp_set_resident_limit(self.handle, n), "picp_set_resident_limit")
+
+    def set_stage2_order(self, order="auto"):
+        """Direction of the second scan of the streaming path: "forward" (as the first scan), "reverse"
+        (against it: reuse of the memory-side cache across the two scans) or "auto" (by input size)."""
+        check(self.lib.picp_set_stage2_order(self.handle, {"auto": -1, "forward": 0, "reverse": 1}[order]),
+              "picp_set_stage2_order")
 
     def resident_capacity(self):
         return int(self.lib.picp_resident_capacity(self.handle))

@@ -18,6 +18,7 @@ struct picp_ctx {
     double* part1;    // [max_blocks1][PICP_S1_DOUBLES]
     double* part2;    // [max_blocks2][PICP_S2_DOUBLES]
     int rows1, rows2; // rows written by the last stage-1 / stage-2 launch
+    int stage2_reverse; // stage 2 walks the arrays against stage 1's direction: 1 always, 0 never, -1 by size
     double* scratch;  // small device scratch: state block + s1 + s2 + misc (see offsets below)
     // association workspace, grown on demand
     int64_t* assoc_count;  // [cap] matches per query row

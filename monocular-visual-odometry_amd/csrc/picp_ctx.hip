@@ -61,6 +61,8 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     // Tuning overrides (workgroups per CU), for experiments only.
     if (const char* e1 = getenv("PICP_STAGE1_WG_PER_CU")) { int k = atoi(e1); if (k >= 1 && k <= 8) ctx->max_blocks1 = k * ctx->num_cus; }
     if (const char* e2 = getenv("PICP_STAGE2_WG_PER_CU")) { int k = atoi(e2); if (k >= 1 && k <= 4) ctx->max_blocks2 = k * ctx->num_cus; }
+    ctx->stage2_reverse = -1; // by size (picp_stage2)
+    if (const char* e3 = getenv("PICP_STAGE2_REVERSE")) ctx->stage2_reverse = atoi(e3) != 0;
     hipError_t e = hipMalloc(&ctx->part1, sizeof(double) * PICP_S1_DOUBLES * ctx->max_blocks1);
     if (e == hipSuccess) e = hipMalloc(&ctx->part2, sizeof(double) * PICP_S2_DOUBLES * ctx->max_blocks2);
     if (e == hipSuccess) e = hipMalloc(&ctx->scratch, sizeof(double) * SCR_DOUBLES);
@@ -109,6 +111,13 @@ int picp_set_resident_limit(picp_ctx* ctx, int64_t max_correspondences) {
     PICP_REQUIRE(ctx != nullptr, "picp_set_resident_limit: null ctx");
     PICP_REQUIRE(max_correspondences >= 0, "picp_set_resident_limit: negative limit");
     ctx->resident_limit = max_correspondences;
+    return PICP_OK;
+}
+
+int picp_set_stage2_order(picp_ctx* ctx, int32_t order) {
+    PICP_REQUIRE(ctx != nullptr, "picp_set_stage2_order: null ctx");
+    PICP_REQUIRE(order >= -1 && order <= 1, "picp_set_stage2_order: order %d is not -1, 0 or 1", (int)order);
+    ctx->stage2_reverse = order;
     return PICP_OK;
 }
 

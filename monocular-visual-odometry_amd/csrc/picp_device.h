@@ -977,20 +977,26 @@ __device__ __forceinline__ Corr2 load2(const double2* __restrict__ u, const doub
 // pair of correspondences is processed, so a wave always has a full step of HBM requests in flight
 // while it computes.  start() issues the very first loads; kernels call it before their prologue
 // (state, partial records), because the addresses depend on nothing but the thread index.
-template <int VEC, int THREADS>
+// REVERSE: every thread visits its grid-stride steps from the last to the first.  A scan that runs
+// against the direction of the scan before it starts with the data that scan read last, which the
+// memory-side cache still holds when the arrays are larger than the cache.
+template <int VEC, int THREADS, bool REVERSE = false>
 struct CorrStream {
     const double *u, *v, *x, *y, *z;
-    int64_t M, stride, tid;
+    int64_t M, stride, tid, head;
     Corr2 A;
     __device__ __forceinline__ void start(const double* u_, const double* v_, const double* x_, const double* y_,
                                           const double* z_, int64_t M_) {
         u = u_, v = v_, x = x_, y = y_, z = z_, M = M_;
         stride = (int64_t)gridDim.x * THREADS;
         tid = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-        if (VEC == 2 && tid < (M >> 1))
+        const int64_t n2 = M >> 1;
+        // the thread's first step: index tid going up, its last grid-stride index going down
+        head = (REVERSE && tid < n2) ? tid + (n2 - 1 - tid) / stride * stride : tid;
+        if (VEC == 2 && tid < n2)
             A = load2(reinterpret_cast<const double2*>(u), reinterpret_cast<const double2*>(v),
                       reinterpret_cast<const double2*>(x), reinterpret_cast<const double2*>(y),
-                      reinterpret_cast<const double2*>(z), tid);
+                      reinterpret_cast<const double2*>(z), head);
     }
     template <typename F>
     __device__ __forceinline__ void run(F&& point) {
@@ -1006,18 +1012,20 @@ struct CorrStream {
             // unconditional (past the end it re-reads the current step, a cache hit whose data is
             // dropped): a load under a lane-dependent branch would make the compiler wait for every
             // outstanding load at the join, the prefetched ones included.
-            int64_t i = tid;
-            if (i < n2) {
+            const int64_t hop = REVERSE ? -stride : stride;
+            auto more = [&](int64_t j) { return REVERSE ? (j >= 0) : (j < n2); };
+            int64_t i = head;
+            if (tid < n2) {
                 Corr2 B;
                 for (;;) {
-                    const int64_t j = i + stride;
-                    const bool hasB = j < n2;
+                    const int64_t j = i + hop;
+                    const bool hasB = more(j);
                     B = load2(u2, v2, x2, y2, z2, hasB ? j : i);
                     point(A.u.x, A.v.x, A.x.x, A.y.x, A.z.x);
                     point(A.u.y, A.v.y, A.x.y, A.y.y, A.z.y);
                     if (!hasB) break;
-                    const int64_t k = j + stride;
-                    const bool hasA = k < n2;
+                    const int64_t k = j + hop;
+                    const bool hasA = more(k);
                     A = load2(u2, v2, x2, y2, z2, hasA ? k : j);
                     point(B.u.x, B.v.x, B.x.x, B.y.x, B.z.x);
                     point(B.u.y, B.v.y, B.x.y, B.y.y, B.z.y);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NT) void stage1_kernel(const double* __restrict__ u
 }
 
 // ---- stage 2 --------------------------------------------------------------------------------
-template <int VEC, bool PINHOLE>
+template <int VEC, bool PINHOLE, bool REVERSE = false>
 __global__ __launch_bounds__(NT2) void stage2_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                     const double* __restrict__ x, const double* __restrict__ y,
                                                     const double* __restrict__ z, int64_t M,
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NT2) void stage2_kernel(const double* __restrict__ 
     __shared__ double lds[(NT2 / 64) * 64];
     __shared__ double s1[PICP_S1_DOUBLES];
     // first correspondences and the stage-1 records are requested together, before anything waits
-    CorrStream<VEC, NT2> stream;
+    CorrStream<VEC, NT2, REVERSE> stream;
     stream.start(u, v, x, y, z, M);
     PartialFold<PICP_S1_DOUBLES, NT2, 8> f1;
     f1.issue(s1part, s1rows, PICP_S1_DOUBLES);
@@ -332,6 +332,14 @@ int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x
     const int s1rows = s1 ? 1 : ctx->rows1;
     auto kern = vec ? (is_pinhole(cam->K) ? stage2_kernel<2, true> : stage2_kernel<2, false>)
                     : (is_pinhole(cam->K) ? stage2_kernel<1, true> : stage2_kernel<1, false>);
+    // Stage 2 against stage 1's direction: it starts with what stage 1 read last and ends with what
+    // the next stage 1 reads first, which the 256 MB memory-side cache still holds when the arrays
+    // are not much larger than it (measured per iteration: 2^23 correspondences 127 -> 112 us,
+    // 12 M 181 -> 169 us; no gain from 2^24 on, a 3 % loss at 2^25; nothing to gain while the arrays fit).
+    const int64_t bytes = M * 5 * (int64_t)sizeof(double);
+    const bool reverse = ctx->stage2_reverse < 0 ? (bytes > (int64_t(64) << 20) && bytes <= (int64_t(512) << 20))
+                                                 : ctx->stage2_reverse != 0;
+    if (vec && reverse) kern = is_pinhole(cam->K) ? stage2_kernel<2, true, true> : stage2_kernel<2, false, true>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p, s1rows,
                        ctx->part2);
     PICP_HIP_CHECK(hipGetLastError());

@@ -341,6 +341,37 @@ def test_large_loop_against_oracle(ctx, loop_path, M):
     assert rel_err(np.array(list(res2.T)).reshape(4, 4), T2) < TOL
 
 
+@pytest.mark.parametrize("M", [2, 3, 1000, 262_149, 700_001, 1 << 21])
+def test_stage2_scan_order(ctx, M):
+    """The streaming loop with its second scan walking the arrays forward and backward: the same pairs
+    are summed in another order, so counts are identical and poses agree to rounding; both agree with
+    the oracle.  Sizes cover a single grid-stride step, ragged last steps and an odd tail."""
+    uv, pw, _ = make_problem(M, seed=11)
+    corr = ctx.soa(uv, pw)
+    sched = yaml_sched(5, disable_stop=True)
+    T_ref, _, h_ref = po.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=5, disable_stop=True),
+                                        record_linear=True)
+    out = {}
+    try:
+        ctx.set_resident_limit(0)
+        for order in ("forward", "reverse"):
+            ctx.set_stage2_order(order)
+            out[order] = ctx.run(corr, np.eye(4), bundled_cam(), sched)
+    finally:
+        ctx.set_resident_limit(None)
+        ctx.set_stage2_order("auto")
+    for order, (res, hist) in out.items():
+        assert res.num_iterations == 5
+        assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h_ref["num_inliers"])), order
+        assert np.array_equal(hist[:, L.H_N_INSIDE].astype(np.int64), np.array(h_ref["n_inside"])), order
+        assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(h_ref["T"])) < TOL, order
+        assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL, order
+    hf, hr = out["forward"][1], out["reverse"][1]
+    for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_N_STAGE1, L.H_N_STAGE2, L.H_KERNEL_THR, L.H_DAMPING):
+        assert np.array_equal(hf[:, col], hr[:, col]), col
+    assert rel_err(hf[:, L.H_H:L.H_H + 36], hr[:, L.H_H:L.H_H + 36]) < 1e-12
+
+
 def test_projective_icp_class_on_bundled_frames(ctx, bundled, tmp_path, monkeypatch):
     """The drop-in class: same call sequence a reference-style driver makes, ground-truth map injected."""
     from tests.bundled import write_data_dir
