@@ -6,7 +6,8 @@
 A step is one complete pose loop: 20 LM iterations (stop test disabled) over a synthetic
 correspondence set that is already resident in HBM.  N = 1 runs the single-GPU configuration
 (2^20 correspondences); N > 1 shards 2^26 correspondences over the N GPUs with two small
-all-reduces per iteration.  Rank 0 prints one JSON line.
+all-reduces per iteration (RCCL, enqueued by the library on the stream of its kernels; the id for
+its communicator travels through the torch.distributed process group).  Rank 0 prints one JSON line.
 
 metric = correspondence-iterations per second, whole job.
 roofline = the dominant kernel against the 8 TB/s HBM3E peak, algorithmic bytes over its mean
@@ -179,6 +180,13 @@ def main():
     pkg = importlib.import_module("monocular-visual-odometry_amd")
     L = pkg._lib
     ctx = pkg.get_context(local_rank)
+
+    if world > 1 and backend == "nccl" and os.environ.get("PICP_BENCH_NATIVE", "1") != "0":
+        # the library's own RCCL communicator: all-reduces on the kernels' stream, whole rounds per call
+        if pkg.sharded.init_native_exchange(ctx):
+            collective = "rccl, enqueued by the library on the kernels' stream"
+        else:
+            collective = "rccl through torch.distributed (the library's communicator could not be set up)"
 
     M = args.corr or ((1 << 20) if world == 1 else (1 << 26))
     lo, hi = pkg.sharded.shard_bounds(M, rank, world)

@@ -37,6 +37,7 @@ extern "C" {
 #define PICP_ERR_HIP (-2)       /* a HIP runtime call failed; see picp_last_error() */
 #define PICP_ERR_CAPACITY (-3)  /* an output buffer is too small; the needed size is reported */
 #define PICP_ERR_NO_DEVICE (-4) /* no usable gfx950 device */
+#define PICP_ERR_COMM (-5)      /* RCCL could not be loaded, or one of its calls failed */
 
 /* Doubles per row of the per-iteration history and of the device state block. */
 #define PICP_HIST_STRIDE 80
@@ -185,6 +186,32 @@ int picp_solve(picp_ctx* ctx, double* state, const picp_schedule* sched, const d
 int picp_profile_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                         const double* z, int64_t M, const double* state, const picp_camera* cam, int32_t reps,
                         double* mean_ms, double* min_ms);
+/* ---- sharded runs: the all-reduces on the ctx's stream ------------------------------------
+ * One process per GPU, every rank holding a contiguous slice of the correspondence arrays and a
+ * replica of the loop state.  The reference has no counterpart (it is one process); what is
+ * exchanged are the sums of :301 and :313-317.  picp_comm_* wrap an RCCL communicator owned by the
+ * ctx (RCCL is loaded at run time; without it these return PICP_ERR_COMM and everything else keeps
+ * working): rank 0 obtains an id with picp_comm_unique_id, the caller hands its PICP_COMM_ID_BYTES
+ * bytes to every rank by whatever means it has (torch.distributed's store, MPI, a file), and all
+ * ranks call picp_comm_init together (it blocks until every rank has joined).
+ * picp_comm_allreduce sums `count` doubles in place over the ranks, enqueued on the ctx's stream.
+ * picp_sharded_rounds enqueues `rounds` rounds of
+ *   stage 1 -> fold into s1 -> all-reduce(s1) -> stage 2 -> fold into s2 -> all-reduce(s2) -> solve
+ * on this rank's slice (s1, s2: device, PICP_S1_DOUBLES / PICP_S2_DOUBLES doubles); with no
+ * communicator the all-reduces are skipped.  Every rank must enqueue the same number of
+ * rounds: the replicated state is identical on all ranks, so a stop flag read back on one is the
+ * same on all (rounds after the stop are no-ops apart from the exchange).  Does not synchronise. */
+#define PICP_COMM_ID_BYTES 128
+int picp_comm_unique_id(void* id_host, int64_t bytes);
+int picp_comm_init(picp_ctx* ctx, const void* id_host, int32_t rank, int32_t world);
+int picp_comm_destroy(picp_ctx* ctx);
+int picp_comm_world(picp_ctx* ctx); /* ranks of the ctx's communicator, 0 without one */
+int picp_comm_allreduce(picp_ctx* ctx, double* buf, int64_t count);
+int picp_sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                        const double* z, int64_t M, double* state, const picp_camera* cam,
+                        const picp_schedule* sched, double* s1, double* s2, double* hist, int32_t hist_rows,
+                        int32_t rounds);
+
 /* Reads the history back (synchronises) and applies the best-iteration rule (:249-257). */
 int picp_finish(picp_ctx* ctx, const double* state, const double* hist, int32_t hist_rows,
                 const double* w_T_c0_host, picp_result* result);

@@ -29,6 +29,8 @@ ST_W_T_C, ST_C_T_W, ST_THR, ST_LAMBDA, ST_IT, ST_STOP = 0, 16, 32, 33, 39, 40
 
 PICP_OK = 0
 PICP_ERR_CAPACITY = -3
+PICP_ERR_COMM = -5
+COMM_ID_BYTES = 128
 
 
 class PicpError(RuntimeError):
@@ -82,6 +84,13 @@ _SIGNATURES = {
     "picp_profile_stage2": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_int32,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "picp_solve": (C.c_int, [_P, _P, C.POINTER(ScheduleStruct), _P, _P, _P, C.c_int32]),
+    "picp_comm_unique_id": (C.c_int, [_P, C.c_int64]),
+    "picp_comm_init": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "picp_comm_destroy": (C.c_int, [_P]),
+    "picp_comm_world": (C.c_int, [_P]),
+    "picp_comm_allreduce": (C.c_int, [_P, _P, C.c_int64]),
+    "picp_sharded_rounds": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
+                                      C.POINTER(ScheduleStruct), _P, _P, _P, C.c_int32, C.c_int32]),
     "picp_finish": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.POINTER(ResultStruct)]),
     "picp_linearize": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_double,
                                  C.c_int32, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_double),

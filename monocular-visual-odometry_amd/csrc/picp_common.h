@@ -40,6 +40,9 @@ struct picp_ctx {
     int resident_aborts;           // launches abandoned so far (each was repeated with the streaming kernels)
     int resident_clean_grid;       // exchange slots hold sentinels for launches of up to this many workgroups
     int resident_last_grid;        // workgroups of the last launch
+    // sharded runs (picp_comm.hip)
+    void* comm;                    // RCCL communicator of this rank, or null
+    int comm_rank, comm_world;
 };
 
 namespace picp {

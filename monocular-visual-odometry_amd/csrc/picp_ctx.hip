@@ -85,6 +85,7 @@ int picp_destroy(picp_ctx* ctx) {
     if (ctx == nullptr) return PICP_OK;
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)picp_comm_destroy(ctx);
     if (ctx->part1) (void)hipFree(ctx->part1);
     if (ctx->part2) (void)hipFree(ctx->part2);
     if (ctx->scratch) (void)hipFree(ctx->scratch);

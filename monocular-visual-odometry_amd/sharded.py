@@ -7,9 +7,16 @@ replica of the loop state.  One iteration is
     stage 2 scan (local)  ->  all-reduce of the inlier set's H, b, sum chi, count (32 doubles)
     solve + schedules (replicated: identical inputs give identical state on every rank)
 
-The two exchanges are `torch.distributed.all_reduce` calls (RCCL over xGMI with the "nccl"
-backend).  The reference needs the global mean of chi before it can choose the inliers
+The reference needs the global mean of chi before it can choose the inliers
 (src/ProjectiveICP.py:301-310), hence two exchanges per iteration rather than one.
+
+Two ways to run the exchanges:
+  * native (`init_native_exchange`): the library owns an RCCL communicator and enqueues
+    ncclAllReduce on the same stream as its kernels, whole rounds per call (`picp_sharded_rounds`):
+    an iteration is one in-order chain on one stream and costs the host one call;
+  * generic: `torch.distributed.all_reduce` between the stage calls (any backend; with gloo the
+    records are staged through host memory).  Used for rehearsals without one GPU per rank and by
+    the CPU tests, and as the fallback when the native communicator cannot be set up.
 """
 from __future__ import annotations
 
@@ -67,6 +74,18 @@ class HipStages:
                                       self.ctx.ptr(s2), self.ctx.ptr(self.hist), self.rows if self.hist is not None else 0),
               "picp_solve")
 
+    def rounds(self, n):
+        """Enqueues n rounds, the all-reduces included when the ctx has a communicator."""
+        check(self.ctx.lib.picp_sharded_rounds(self.ctx.handle, *self._corr_ptrs, self.M, self.ctx.ptr(self.state),
+                                               C.byref(self.cam), C.byref(self.sched), self.ctx.ptr(self.s1),
+                                               self.ctx.ptr(self.s2), self.ctx.ptr(self.hist),
+                                               self.rows if self.hist is not None else 0, int(n)), "picp_sharded_rounds")
+
+    @property
+    def native_exchange(self):
+        """True when the ctx's own communicator covers the exchange (or there is nothing to exchange)."""
+        return int(self.ctx.lib.picp_comm_world(self.ctx.handle)) >= 1
+
     def stopped(self):
         return bool(self.state[_lib.ST_STOP].item() != 0.0)
 
@@ -76,6 +95,40 @@ class HipStages:
                                        self.pose.ctypes.data_as(C.c_void_p), C.byref(res)), "picp_finish")
         hist = self.hist[: res.num_iterations].cpu().numpy() if self.hist is not None else None
         return res, hist
+
+
+def init_native_exchange(ctx, group=None):
+    """Gives ``ctx`` an RCCL communicator over the ranks of ``group`` (default: the world), for
+    `HipStages.rounds`.  The id RCCL needs is made on rank 0 and handed round through the existing
+    process group, whatever its backend.  Collective: every rank must call it.  Returns True when all
+    ranks have their communicator; otherwise every rank is left without one (and the generic
+    exchange is used)."""
+    import torch
+    import torch.distributed as dist
+    lib = ctx.lib
+    if int(lib.picp_comm_world(ctx.handle)) >= 1:
+        return True
+    multi = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if multi else 0
+    world = dist.get_world_size(group) if multi else 1
+    box = [None]
+    if rank == 0:
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        if lib.picp_comm_unique_id(buf, _lib.COMM_ID_BYTES) == _lib.PICP_OK:
+            box[0] = bytes(buf.raw)
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if box[0] is None:
+        return False
+    ok = lib.picp_comm_init(ctx.handle, box[0], rank, world) == _lib.PICP_OK
+    if world > 1:
+        on_gpu = dist.get_backend(group) == "nccl"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctx.device if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = bool(flag.item())
+    if not ok:
+        lib.picp_comm_destroy(ctx.handle)
+    return ok
 
 
 def _all_reduce_sum(t, group, through_host):
@@ -88,7 +141,8 @@ def _all_reduce_sum(t, group, through_host):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
-def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=False, through_host=None):
+def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=False, through_host=None,
+                native=None):
     """Drives ``stages`` (this rank's shard) through the loop with the two all-reduces per iteration.
 
     ``stages`` provides state_init / stage1 / stage2 / solve / stopped / finish (see HipStages).
@@ -102,11 +156,21 @@ def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=
     num_iterations rounds when ``disable_stop`` is set.  The flag is identical on all ranks, so every
     rank leaves the loop after the same round.
 
+    ``native``: let the library enqueue whole rounds, its own RCCL all-reduces included
+    (`HipStages.rounds`).  Default: when ``stages`` can do that -- the ctx has a communicator
+    (`init_native_exchange`) or there is only one shard; otherwise the generic loop below runs.
+
     ``through_host``: stage the two records through host memory for the all-reduce.  Default: only
     when the process group's backend is not "nccl" (RCCL reduces device buffers in place; the gloo
     backend is a CPU transport and is used for rehearsals on machines without one GPU per rank)."""
     import torch.distributed as dist
     exchange = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if native is None:
+        native = getattr(stages, "native_exchange", False) or (not exchange and hasattr(stages, "rounds"))
+    if native:
+        if exchange and not getattr(stages, "native_exchange", False):
+            raise _lib.PicpError("run_sharded(native=True) needs init_native_exchange on every rank first")
+        return _run_native(stages, int(num_iterations), check_every, disable_stop)
     if through_host is None:
         through_host = exchange and dist.get_backend(group) != "nccl"
     stages.state_init()
@@ -126,6 +190,21 @@ def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=
             if stages.stopped():
                 break
             next_check = rounds + (1 if disable_stop else check_every)
+    return stages.finish()
+
+
+def _run_native(stages, total, check_every, disable_stop):
+    """The loop with whole rounds enqueued by the library (its own all-reduces in between, if the ctx
+    has a communicator).  Same stop protocol as the generic loop: the flag is read back after every
+    chunk of rounds, all ranks read the same value and so enqueue the same number of rounds."""
+    stages.state_init()
+    rounds = 0
+    while total > 0 and rounds < 2 * total:
+        n = (total if rounds == 0 else 1) if disable_stop else min(check_every, 2 * total - rounds)
+        stages.rounds(n)
+        rounds += n
+        if stages.stopped():
+            break
     return stages.finish()
 
 

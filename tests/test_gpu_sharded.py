@@ -34,13 +34,44 @@ def test_single_shard_stages_equal_one_call_loop():
     corr = ctx.soa(uv, pw)
     res, hist = ctx.run(corr, np.eye(4), cam, sched)
     stages = pkg.sharded.HipStages(ctx, corr, np.eye(4), cam, sched)
-    res2, hist2 = pkg.sharded.run_sharded(stages, 25, check_every=4)
+    res2, hist2 = pkg.sharded.run_sharded(stages, 25, check_every=4, native=False)     # stage by stage from Python
+    stages_n = pkg.sharded.HipStages(ctx, corr, np.eye(4), cam, sched)
+    res3, hist3 = pkg.sharded.run_sharded(stages_n, 25, check_every=4)                 # whole rounds per call
+    assert res3.num_iterations == res2.num_iterations and res3.best_index == res2.best_index
+    assert np.array_equal(hist3, hist2)
     assert res2.num_iterations == res.num_iterations and res2.best_index == res.best_index
     assert np.array_equal(hist2[:, L.H_NUM_INLIERS], hist[:, L.H_NUM_INLIERS])
     assert rel_err(hist2[:, L.H_T:L.H_T + 16], hist[:, L.H_T:L.H_T + 16]) < 1e-12
     T_ref, valid_ref, h_ref = po.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=25))
     assert hist2[:, L.H_NUM_INLIERS].astype(int).tolist() == h_ref["num_inliers"]
     assert rel_err(np.array(list(res2.T)).reshape(4, 4), T_ref) < 1e-9
+
+
+def test_rounds_with_the_library_s_own_rccl_communicator():
+    """A communicator of one rank on the ctx: picp_sharded_rounds then issues its two ncclAllReduce per
+    round on the ctx's stream (with one rank they leave the records as they are), so the run must
+    equal the run without a communicator bit for bit; picp_comm_allreduce alone leaves a buffer unchanged."""
+    ctx = L.Context(0)
+    assert pkg.sharded.init_native_exchange(ctx)
+    assert int(ctx.lib.picp_comm_world(ctx.handle)) == 1
+    buf = ctx.to_device(np.arange(32, dtype=np.float64) * 0.1)
+    L.check(ctx.lib.picp_comm_allreduce(ctx.handle, ctx.ptr(buf), 32), "picp_comm_allreduce")
+    assert np.array_equal(buf.cpu().numpy(), np.arange(32, dtype=np.float64) * 0.1)
+    uv, pw, _ = make_problem(300_001, seed=4)
+    cam, sched = _cam_sched(12, False)
+    corr = ctx.soa(uv, pw)
+    stages = pkg.sharded.HipStages(ctx, corr, np.eye(4), cam, sched)
+    assert stages.native_exchange
+    res, hist = pkg.sharded.run_sharded(stages, 12, check_every=4)
+    plain = pkg.get_context(0)
+    res0, hist0 = pkg.sharded.run_sharded(pkg.sharded.HipStages(plain, corr, np.eye(4), cam, sched), 12, native=False)
+    assert res.num_iterations == res0.num_iterations and np.array_equal(hist, hist0)
+    assert np.array_equal(np.array(list(res.T)), np.array(list(res0.T)))
+    T_ref, _, h_ref = po.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=12))
+    assert hist[:, L.H_NUM_INLIERS].astype(int).tolist() == h_ref["num_inliers"]
+    assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < 1e-9
+    L.check(ctx.lib.picp_comm_destroy(ctx.handle), "picp_comm_destroy")
+    assert int(ctx.lib.picp_comm_world(ctx.handle)) == 0
 
 
 def _rank(rank, world, port, M, num_iterations, out):
