@@ -115,3 +115,45 @@ def test_loop_invariances_at_full_size():
     assert np.array_equal(hist_p[:, L.H_NUM_INLIERS], hist[:, L.H_NUM_INLIERS])
     assert rel_err(hist_p[:, L.H_T:L.H_T + 16], hist[:, L.H_T:L.H_T + 16]) < 1e-11
     assert np.max(np.abs(np.array(list(res.T)).reshape(4, 4) - po.v2T(list(TRUE_V)))) < 1e-3
+
+
+def test_more_than_2_to_31_correspondences():
+    """Maximum sizes: 2 049 copies of a ragged 1 048 583-correspondence block = 2 148 546 567
+    correspondences (86 GB of float64 planes, an odd count beyond 2^31, so element indices and byte
+    offsets leave 32 bits).  Sums over K copies are K times the block's sums, so against the block
+    run with the damping divided by K (the solve is (K H + lambda I) dx = -K b): in-image and inlier
+    counts exactly K times the block's, thresholds identical, errors and poses within 1e-9 -- and
+    the block itself is checked against the oracle."""
+    import torch
+    free, _ = torch.cuda.mem_get_info(0)
+    m, K = 1_048_583, 2049
+    M = m * K
+    if free < 5 * 8 * M + (8 << 30):
+        pytest.skip(f"needs {5 * 8 * M / 2**30:.0f} GiB of free device memory")
+    assert M > 2**31 and M % 2 == 1
+    ctx = pkg.get_context(0)
+    uv, pw, _ = make_problem(m, seed=31)
+    block = ctx.soa(uv, pw)
+    planes = ctx.empty((5, L._pad32(M)))
+    for k in range(5):
+        planes[k][:M].view(K, m)[:] = block[k]
+    corr = [planes[k][:M] for k in range(5)]
+    n_it, lam = 4, 64.0
+    cam = L.camera_struct([[180, 0, 320], [0, 180, 240], [0, 0, 1]], 640, 480)
+    big = L.schedule_struct(n_it, 10, 1000, 10, 2000, lam, lam, lam, True)
+    small = L.schedule_struct(n_it, 10, 1000, 10, 2000, lam / K, lam / K, lam / K, True)
+    res_b, hist_b = ctx.run(corr, np.eye(4), cam, big)
+    res_s, hist_s = ctx.run(block, np.eye(4), cam, small)
+    assert res_b.num_iterations == n_it and res_s.num_iterations == n_it
+    for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_N_STAGE1, L.H_N_STAGE2):
+        assert np.array_equal(hist_b[:, col], K * hist_s[:, col]), col
+    assert np.array_equal(hist_b[:, L.H_KERNEL_THR], hist_s[:, L.H_KERNEL_THR])
+    assert rel_err(hist_b[:, L.H_ERROR], hist_s[:, L.H_ERROR]) < 1e-9
+    assert rel_err(hist_b[:, L.H_H:L.H_H + 36], K * hist_s[:, L.H_H:L.H_H + 36]) < 1e-9
+    assert rel_err(hist_b[:, L.H_T:L.H_T + 16], hist_s[:, L.H_T:L.H_T + 16]) < 1e-9
+    assert rel_err(np.array(list(res_b.T)), np.array(list(res_s.T))) < 1e-9
+    params = po.IcpParams(num_iterations=n_it, disable_stop=True, damping=lam / K, min_damping=lam / K,
+                          max_damping=lam / K)
+    T_ref, _, h_ref = po.projective_icp(uv, pw, np.eye(4), params)
+    assert hist_s[:, L.H_NUM_INLIERS].astype(np.int64).tolist() == h_ref["num_inliers"]
+    assert rel_err(np.array(list(res_s.T)).reshape(4, 4), T_ref) < 1e-9
