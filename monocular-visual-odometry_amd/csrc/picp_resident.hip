@@ -426,7 +426,11 @@ __global__ __launch_bounds__(NTB, (R <= BATCHED_THREE_PER_CU_MAX_R) ? 3 : 2) voi
             __syncthreads();
         }
         double* row = (myhist != nullptr && it < hist_rows) ? myhist + (size_t)it * PICP_HIST_STRIDE : nullptr;
+        // The tail is a latency chain on single lanes while the other workgroups of the CU stream
+        // through their stages: its waves go first whenever they can issue (2 % on 4 096 x 2 048).
+        __builtin_amdgcn_s_setprio(3);
         (void)solve_step(st, s1, s2, sc, row, &sh);
+        __builtin_amdgcn_s_setprio(0);
     }
     if (threadIdx.x == 0) {
         picp_result r;
