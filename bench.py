@@ -272,7 +272,9 @@ def main():
                                     f"synthetic single-pose projective ICP, {M} correspondences sharded over "
                                     f"{world} GPU(s), 20 LM iterations, 2 all-reduces per iteration"),
                        "correspondences": M, "lm_iterations": ITERATIONS,
-                       "device_path": "single launch, register-resident" if resident else "streaming stage launches",
+                       "device_path": ("single launch, register-resident" if resident else
+                                       "single launch, arrays streamed twice per iteration" if world == 1 else
+                                       "streaming stage launches"),
                        "collective": collective,
                        "final_pose_error": float(np.max(np.abs(np.array(list(res.T)).reshape(4, 4) - true_pose())))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

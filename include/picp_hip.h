@@ -119,12 +119,16 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
              int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched,
              double* state, double* hist, int32_t hist_rows, picp_result* result);
 
-/* picp_run has two device paths with the same results (sums differ only in the order of additions):
- * up to picp_resident_capacity(ctx) correspondences the whole loop is ONE launch that reads the five
- * arrays once and keeps them in registers and LDS, exchanging the two per-iteration sums of :301 and
- * :313-317 between workgroups inside the kernel; larger inputs stream the arrays twice per iteration through
- * separate launches.  picp_set_resident_limit lowers the switch point (0 = always stream); the
- * capacity is a property of the device (CUs x threads x registers). */
+/* picp_run has three device paths with the same results (sums differ only in the order of additions):
+ *  - up to picp_resident_capacity(ctx) correspondences the whole loop is ONE launch that reads the
+ *    five arrays once and keeps them in registers and LDS, exchanging the two per-iteration sums of
+ *    :301 and :313-317 between workgroups inside the kernel;
+ *  - larger inputs (16-byte aligned arrays) run the whole loop in one launch as well, with the arrays
+ *    streamed from memory twice per iteration and the same in-kernel exchange;
+ *  - otherwise, and as the fallback of the other two, every iteration is three launches (two scans
+ *    and the solve step).
+ * picp_set_resident_limit lowers the switch point between the first two (0 = always the per-iteration
+ * launches); the capacity is a property of the device (CUs x threads x registers). */
 int picp_set_resident_limit(picp_ctx* ctx, int64_t max_correspondences);
 int64_t picp_resident_capacity(picp_ctx* ctx);
 /* The single launch waits for all of its workgroups at every exchange, with a bound on each wait.  If

@@ -40,6 +40,7 @@ struct picp_ctx {
     int resident_aborts;           // launches abandoned so far (each was repeated with the streaming kernels)
     int resident_clean_grid;       // exchange slots hold sentinels for launches of up to this many workgroups
     int resident_last_grid;        // workgroups of the last launch
+    int64_t persistent_limit;      // largest M the streaming single-launch loop is used for (0: never)
     // sharded runs (picp_comm.hip)
     void* comm;                    // RCCL communicator of this rank, or null
     int comm_rank, comm_world;
@@ -67,6 +68,21 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
                      const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
                      const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
                      hipEvent_t e1);
+
+int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                       const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
+                       const picp_schedule* sched, double* hist, int hist_rows, double* host_state);
+
+// Whether the second scan of an iteration walks the arrays against the first one's direction: it
+// then starts with what stage 1 read last and ends with what the next stage 1 reads first, which
+// the 256 MB memory-side cache still holds when the arrays are not much larger than it (measured per
+// iteration: 2^23 correspondences 127 -> 112 us, 12 M 181 -> 169 us; no gain from 2^24 on, a 3 % loss
+// at 2^25; nothing to gain while the arrays fit the L2s).
+inline bool stage2_reverse(const picp_ctx* ctx, int64_t M) {
+    const int64_t bytes = M * 5 * (int64_t)sizeof(double);
+    return ctx->stage2_reverse < 0 ? (bytes > (int64_t(64) << 20) && bytes <= (int64_t(512) << 20))
+                                   : ctx->stage2_reverse != 0;
+}
 
 struct DeviceGuard {
     int prev = -1;

@@ -71,6 +71,8 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * 3 * PICP_S2_DOUBLES * ctx->num_cus);
     ctx->resident_limit = INT64_MAX; // i.e. whatever fits (resident_capacity)
     ctx->resident_spin_limit = 1u << 18;
+    ctx->persistent_limit = INT64_MAX;
+    if (const char* ep = getenv("PICP_PERSISTENT_LIMIT")) ctx->persistent_limit = atoll(ep);
     if (const char* er = getenv("PICP_RESIDENT")) { if (atoi(er) == 0) ctx->resident_limit = 0; }
     if (const char* es = getenv("PICP_RESIDENT_SPIN_LIMIT")) { int k = atoi(es); if (k >= 0) ctx->resident_spin_limit = (unsigned)k; }
     if (e != hipSuccess) {

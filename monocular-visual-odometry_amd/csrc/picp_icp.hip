@@ -332,13 +332,7 @@ int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x
     const int s1rows = s1 ? 1 : ctx->rows1;
     auto kern = vec ? (is_pinhole(cam->K) ? stage2_kernel<2, true> : stage2_kernel<2, false>)
                     : (is_pinhole(cam->K) ? stage2_kernel<1, true> : stage2_kernel<1, false>);
-    // Stage 2 against stage 1's direction: it starts with what stage 1 read last and ends with what
-    // the next stage 1 reads first, which the 256 MB memory-side cache still holds when the arrays
-    // are not much larger than it (measured per iteration: 2^23 correspondences 127 -> 112 us,
-    // 12 M 181 -> 169 us; no gain from 2^24 on, a 3 % loss at 2^25; nothing to gain while the arrays fit).
-    const int64_t bytes = M * 5 * (int64_t)sizeof(double);
-    const bool reverse = ctx->stage2_reverse < 0 ? (bytes > (int64_t(64) << 20) && bytes <= (int64_t(512) << 20))
-                                                 : ctx->stage2_reverse != 0;
+    const bool reverse = stage2_reverse(ctx, M);
     if (vec && reverse) kern = is_pinhole(cam->K) ? stage2_kernel<2, true, true> : stage2_kernel<2, false, true>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p, s1rows,
                        ctx->part2);
@@ -480,6 +474,20 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
             return PICP_OK;
         }
         // the launch was abandoned at a grid-wide wait (device shared with other work): start over
+        ctx->resident_aborts += 1;
+    }
+    // Larger inputs: the same single launch with the arrays streamed from memory every iteration.
+    if (M > resident_capacity(ctx) && ctx->resident_limit > 0 && M <= ctx->persistent_limit &&
+        sched->num_iterations > 0 && aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z)) {
+        if (int rc = enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
+                                        ctx->pinned))
+            return rc;
+        PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned[ST_STOP] != 0.0) {
+            result_from_state(ctx->pinned, w_T_c0_host, result);
+            resident_refill(ctx);
+            return PICP_OK;
+        }
         ctx->resident_aborts += 1;
     }
     if (int rc = picp_state_init(ctx, state, w_T_c0_host, sched)) return rc;

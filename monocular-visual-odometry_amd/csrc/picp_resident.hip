@@ -315,6 +315,94 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     }
 }
 
+// ---- the whole loop in one launch for inputs beyond the register files ----------------------------
+// The same loop with the correspondences streamed from memory twice per iteration (as the stage
+// kernels of picp_icp.hip do) instead of held on chip: one 512-thread workgroup per CU walks its
+// grid-stride share forward in stage 1 and, for inputs the memory-side cache can help with, backward
+// in stage 2 (so each scan starts with what the previous one read last), and the two sums are exchanged between the workgroups inside the kernel.
+// Against three launches per iteration this saves the launch ramps and gaps, the record folds in the
+// prologues and the separate solve launch: about 10 us per iteration, which matters while a scan
+// takes tens of microseconds.  The first loads of the next scan are issued before the exchange
+// that precedes it, so their latency is hidden behind it.
+template <bool PINHOLE, bool REVERSE>
+__global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __restrict__ u, const double* __restrict__ v,
+                                                            const double* __restrict__ x, const double* __restrict__ y,
+                                                            const double* __restrict__ z, int64_t M,
+                                                            double* __restrict__ state, StartPose pose0, CameraK cam,
+                                                            picp_schedule sc, GridExchange gx, double* __restrict__ hist,
+                                                            int hist_rows, double* __restrict__ host_state) {
+    __shared__ double st[PICP_STATE_DOUBLES];
+    __shared__ double lds[NTR];
+    __shared__ double lds_fold[NTR];
+    __shared__ double s1[PICP_S1_DOUBLES];
+    __shared__ double s2[PICP_S2_DOUBLES];
+    __shared__ double row[PICP_HIST_STRIDE];
+    __shared__ int flag;
+    __shared__ StepShared sh;
+    CorrStream<2, NTR, false> fwd;
+    CorrStream<2, NTR, REVERSE> rev; // stage 2's direction: see stage2_reverse()
+    fwd.start(u, v, x, y, z, M);
+    if (threadIdx.x == 0) {
+        init_state(st, pose0.m, sc.kernel_threshold, sc.damping, sc.num_iterations);
+        flag = 0;
+    }
+    __syncthreads();
+
+    unsigned epoch = 0;
+    while (st[ST_STOP] == 0.0) {
+        double T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = uniform(st[ST_C_T_W + i]);
+        const double thr = uniform(st[ST_THR]);
+        const bool all = (st[ST_MODE] != 0.0);
+        const int it = (int)st[ST_IT];
+
+        Stage1Sums a{0.0, 0u, 0u};
+        fwd.run([&](double mu, double mv, double px, double py, double pz) {
+            stage1_point<PINHOLE>(T, cam, thr, mu, mv, px, py, pz, a);
+        });
+        rev.start(u, v, x, y, z, M); // in flight during the exchange
+        {
+            const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
+            const double tot = block_sum<3, NTR, false>(vals, lds);
+            double g = tot;
+            if (gridDim.x > 1 && !grid_total<3, 2>(tot, g, gx, epoch, lds_fold, &flag)) return;
+            if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < 3) ? g : 0.0;
+            __syncthreads();
+        }
+        const double n1 = s1[S1_COUNT]; // identical in every workgroup, so the branch below is grid-uniform
+        if (n1 != 0.0) {
+            const double mean = uniform(s1[S1_SUM_CHI] / n1); // np.mean, src/ProjectiveICP.py:301
+            Stage2Sums s;
+            s.clear();
+            rev.run([&](double mu, double mv, double px, double py, double pz) {
+                stage2_point<PINHOLE>(T, cam, thr, mean, all, mu, mv, px, py, pz, s);
+            });
+            fwd.start(u, v, x, y, z, M); // the next iteration's first loads
+            double vals[S2_USED];
+            pack_sets(s, vals);
+            const double tot = block_sum<S2_USED, NTR, false>(vals, lds);
+            double g = tot;
+            if (gridDim.x > 1 && !grid_total<S2_USED, 16>(tot, g, gx, epoch, lds_fold, &flag)) return;
+            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = (threadIdx.x < S2_USED) ? g : 0.0;
+            __syncthreads();
+        } else {
+            fwd.start(u, v, x, y, z, M);
+            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = 0.0; // :300
+            __syncthreads();
+        }
+
+        const bool record = (blockIdx.x == 0 && hist != nullptr && it < hist_rows);
+        const bool advanced = solve_step(st, s1, s2, sc, record ? row : nullptr, &sh);
+        if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
+            hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < PICP_STATE_DOUBLES) {
+        state[threadIdx.x] = st[threadIdx.x];
+        if (host_state != nullptr) host_state[threadIdx.x] = st[threadIdx.x];
+    }
+}
+
 // ---- one problem per workgroup, correspondences held on chip ------------------------------------
 // The same loop body for a batch of independent problems (problem p = correspondences
 // [offsets[p], offsets[p+1])): a 256-thread workgroup per problem, R correspondences per thread,
@@ -545,6 +633,31 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
         break;
     }
 #undef PICP_RESIDENT_CASE
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+// The streaming single-launch loop (icp_persistent_kernel) for 16-byte aligned arrays of any length.
+// Same completion protocol as enqueue_resident.
+int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                       const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
+                       const picp_schedule* sched, double* hist, int hist_rows, double* host_state) {
+    PICP_REQUIRE(M > 0, "persistent loop: no correspondences");
+    const int64_t steps = ((M >> 1) + NTR - 1) / NTR; // workgroups needed for one grid-stride step
+    const int grid = (int)(steps < 1 ? 1 : (steps > resident_grid(ctx) ? resident_grid(ctx) : steps));
+    if (host_state != nullptr) host_state[ST_STOP] = 0.0;
+    StartPose pose;
+    memcpy(pose.m, w_T_c0_host, sizeof(pose.m));
+    if (ctx->resident_clean_grid < grid) fill_slots(ctx, grid);
+    ctx->resident_clean_grid = 0;
+    ctx->resident_last_grid = grid;
+    const CameraK c = camera_of(cam);
+    GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
+    const bool pin = is_pinhole(cam->K);
+    auto kern = stage2_reverse(ctx, M) ? (pin ? icp_persistent_kernel<true, true> : icp_persistent_kernel<false, true>)
+                                       : (pin ? icp_persistent_kernel<true, false> : icp_persistent_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, u, v, x, y, z, M, state, pose, c, *sched, gx, hist,
+                       hist_rows, host_state);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
 }

@@ -117,13 +117,14 @@ def test_loop_invariances_at_full_size():
     assert np.max(np.abs(np.array(list(res.T)).reshape(4, 4) - po.v2T(list(TRUE_V)))) < 1e-3
 
 
-def test_more_than_2_to_31_correspondences():
+@pytest.mark.parametrize("path", ["one launch", "stage launches"])
+def test_more_than_2_to_31_correspondences(path):
     """Maximum sizes: 2 049 copies of a ragged 1 048 583-correspondence block = 2 148 546 567
     correspondences (86 GB of float64 planes, an odd count beyond 2^31, so element indices and byte
     offsets leave 32 bits).  Sums over K copies are K times the block's sums, so against the block
     run with the damping divided by K (the solve is (K H + lambda I) dx = -K b): in-image and inlier
     counts exactly K times the block's, thresholds identical, errors and poses within 1e-9 -- and
-    the block itself is checked against the oracle."""
+    the block itself is checked against the oracle.  Both of picp_run's paths for such sizes."""
     import torch
     free, _ = torch.cuda.mem_get_info(0)
     m, K = 1_048_583, 2049
@@ -142,7 +143,11 @@ def test_more_than_2_to_31_correspondences():
     cam = L.camera_struct([[180, 0, 320], [0, 180, 240], [0, 0, 1]], 640, 480)
     big = L.schedule_struct(n_it, 10, 1000, 10, 2000, lam, lam, lam, True)
     small = L.schedule_struct(n_it, 10, 1000, 10, 2000, lam / K, lam / K, lam / K, True)
-    res_b, hist_b = ctx.run(corr, np.eye(4), cam, big)
+    try:
+        ctx.set_resident_limit(None if path == "one launch" else 0)
+        res_b, hist_b = ctx.run(corr, np.eye(4), cam, big)
+    finally:
+        ctx.set_resident_limit(None)
     res_s, hist_s = ctx.run(block, np.eye(4), cam, small)
     assert res_b.num_iterations == n_it and res_s.num_iterations == n_it
     for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_N_STAGE1, L.H_N_STAGE2):

@@ -25,11 +25,13 @@ def ctx():
     return pkg.get_context(0)
 
 
-@pytest.fixture(params=["streaming", "resident"])
+@pytest.fixture(params=["streaming", "resident", "persistent"])
 def loop_path(request, ctx):
-    """picp_run's two device paths: per-iteration stage launches that stream the arrays, and the
-    single launch that keeps the correspondences in registers."""
-    ctx.set_resident_limit(0 if request.param == "streaming" else None)
+    """picp_run's three device paths: per-iteration stage launches that stream the arrays, the single
+    launch that keeps the correspondences in registers, and the single launch that streams them
+    (normally chosen beyond the on-chip capacity; with the on-chip limit at one correspondence it
+    takes every larger input)."""
+    ctx.set_resident_limit({"streaming": 0, "resident": None, "persistent": 1}[request.param])
     yield request.param
     ctx.set_resident_limit(None)
 
@@ -142,7 +144,7 @@ def test_linearize_edge_cases(ctx):
 
 @pytest.mark.parametrize("path", ["kernels", "workgroup", "workgroup_reread"])
 def test_full_loop_reference_synthetic(ctx, path, loop_path):
-    if path != "kernels" and loop_path == "resident":
+    if path != "kernels" and loop_path != "streaming":
         pytest.skip("the batched kernels do not depend on picp_run's path")
     g = load_golden("ref_synthetic.npz")
     cam = bundled_cam()
@@ -172,7 +174,7 @@ def test_full_loop_reference_synthetic(ctx, path, loop_path):
 @pytest.mark.parametrize("path", ["run", "batched_on_chip", "batched_reread"])
 def test_full_loop_general_camera_matrix(ctx, path, loop_path):
     """A camera matrix with skew and unequal focal lengths takes the kernels' general-K instantiations."""
-    if path != "run" and loop_path == "resident":
+    if path != "run" and loop_path != "streaming":
         pytest.skip("the batched kernels do not depend on picp_run's path")
     g = load_golden("ref_general_camera.npz")
     cam = L.camera_struct(g["K"], 640, 480)
@@ -341,6 +343,28 @@ def test_large_loop_against_oracle(ctx, loop_path, M):
     assert rel_err(np.array(list(res2.T)).reshape(4, 4), T2) < TOL
 
 
+def test_beyond_the_on_chip_capacity_one_launch_streams(ctx):
+    """Just above the on-chip capacity picp_run switches by itself to the single launch that streams
+    the arrays: same counts as the oracle, poses within 1e-9, and the same as the stage launches."""
+    M = ctx.resident_capacity() + 4099
+    uv, pw, _ = make_problem(M, seed=21)
+    corr = ctx.soa(uv, pw)
+    sched = yaml_sched(3, disable_stop=True)
+    T_ref, _, h_ref = po.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=3, disable_stop=True))
+    res, hist = ctx.run(corr, np.eye(4), bundled_cam(), sched)
+    try:
+        ctx.set_resident_limit(0)
+        res_s, hist_s = ctx.run(corr, np.eye(4), bundled_cam(), sched)
+    finally:
+        ctx.set_resident_limit(None)
+    assert res.num_iterations == 3 and ctx.resident_aborts() == 0
+    assert hist[:, L.H_NUM_INLIERS].astype(np.int64).tolist() == h_ref["num_inliers"]
+    assert np.array_equal(hist[:, L.H_NUM_INLIERS], hist_s[:, L.H_NUM_INLIERS])
+    assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(h_ref["T"])) < TOL
+    assert rel_err(hist[:, L.H_T:L.H_T + 16], hist_s[:, L.H_T:L.H_T + 16]) < 1e-12
+    assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
+
+
 @pytest.mark.parametrize("M", [2, 3, 1000, 262_149, 700_001, 1 << 21])
 def test_stage2_scan_order(ctx, M):
     """The streaming loop with its second scan walking the arrays forward and backward: the same pairs
@@ -400,13 +424,15 @@ def test_projective_icp_class_on_bundled_frames(ctx, bundled, tmp_path, monkeypa
         assert rel_err(cam.get_c_T_w(), np.linalg.inv(T)) < 1e-14
 
 
-def test_single_launch_loop_gives_up_cleanly(monkeypatch):
+@pytest.mark.parametrize("limit", [None, 1])
+def test_single_launch_loop_gives_up_cleanly(monkeypatch, limit):
     """With a wait bound of zero polls the single-launch loop abandons its launch as soon as one record
     is not there at first look; picp_run must then repeat the loop with the streaming kernels and
     return the same result.  (Whether a given launch gives up depends on timing; with 137 workgroups and
     12 exchanges per run most runs do.)"""
     monkeypatch.setenv("PICP_RESIDENT_SPIN_LIMIT", "0")
     impatient = L.Context(0)
+    impatient.set_resident_limit(limit)          # None: the on-chip loop; 1: the streaming single launch
     monkeypatch.delenv("PICP_RESIDENT_SPIN_LIMIT")
     M = 70_000
     uv, pw, _ = make_problem(M, seed=3)
@@ -423,7 +449,7 @@ def test_single_launch_loop_gives_up_cleanly(monkeypatch):
 
 
 def test_single_launch_loop_equals_streaming_loop_on_random_problems(ctx):
-    """picp_run's two device paths on 150 random problems (sizes 1 .. 60 000, good and bad start poses,
+    """picp_run's three device paths on 150 random problems (sizes 1 .. 60 000, good and bad start poses,
     tight and loose thresholds, so that zero-inlier iterations, the fallback to the stage-1 set and
     early stops all occur): identical iteration counts, inlier counts, thresholds and damping; poses
     within 1e-9."""
@@ -440,16 +466,17 @@ def test_single_launch_loop_equals_streaming_loop_on_random_problems(ctx):
             corr = ctx.soa(uv, pw)
             ctx.set_resident_limit(0)
             res_s, hist_s = ctx.run(corr, start, cam, sched)
-            ctx.set_resident_limit(None)
-            res_r, hist_r = ctx.run(corr, start, cam, sched)
-            assert res_r.num_iterations == res_s.num_iterations, k
-            assert bool(res_r.valid) == bool(res_s.valid), k
-            for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_KERNEL_THR, L.H_DAMPING, L.H_N_STAGE1, L.H_N_STAGE2,
-                        L.H_USED_STAGE2, L.H_DONE):
-                assert np.array_equal(hist_r[:, col], hist_s[:, col]), (k, col)
-            assert rel_err(hist_r[:, L.H_T:L.H_T + 16], hist_s[:, L.H_T:L.H_T + 16]) < TOL, k
-            if res_r.best_index == res_s.best_index:
-                assert rel_err(np.array(list(res_r.T)), np.array(list(res_s.T))) < TOL, k
+            for limit in (None, 1):          # on-chip single launch, streaming single launch
+                ctx.set_resident_limit(limit)
+                res_r, hist_r = ctx.run(corr, start, cam, sched)
+                assert res_r.num_iterations == res_s.num_iterations, (k, limit)
+                assert bool(res_r.valid) == bool(res_s.valid), (k, limit)
+                for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_KERNEL_THR, L.H_DAMPING, L.H_N_STAGE1, L.H_N_STAGE2,
+                            L.H_USED_STAGE2, L.H_DONE):
+                    assert np.array_equal(hist_r[:, col], hist_s[:, col]), (k, limit, col)
+                assert rel_err(hist_r[:, L.H_T:L.H_T + 16], hist_s[:, L.H_T:L.H_T + 16]) < TOL, (k, limit)
+                if res_r.best_index == res_s.best_index:
+                    assert rel_err(np.array(list(res_r.T)), np.array(list(res_s.T))) < TOL, (k, limit)
             seen_redo += int(np.any((hist_s[:, L.H_USED_STAGE2] == 0) & (hist_s[:, L.H_N_STAGE1] > 0)))
             seen_zero += int(np.any(hist_s[:, L.H_NUM_INLIERS] == 0))
     finally:
