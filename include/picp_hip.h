@@ -137,7 +137,8 @@ int64_t picp_resident_capacity(picp_ctx* ctx);
 int picp_resident_aborts(picp_ctx* ctx);
 /* Timing aid for benchmarks: runs the single-launch loop `reps` times from w_T_c0_host, each launch
  * bracketed by HIP events bound to that dispatch, and reports the mean and minimum kernel duration
- * in milliseconds.  M must not exceed picp_resident_capacity.  Synchronises. */
+ * in milliseconds.  Beyond picp_resident_capacity it times the single launch that streams the arrays
+ * (16-byte aligned arrays).  Synchronises. */
 int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
                      const picp_schedule* sched, double* state, int32_t reps, double* mean_ms, double* min_ms);

@@ -71,7 +71,8 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
 
 int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                        const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
-                       const picp_schedule* sched, double* hist, int hist_rows, double* host_state);
+                       const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
+                       hipEvent_t e1);
 
 // Whether the second scan of an iteration walks the arrays against the first one's direction: it
 // then starts with what stage 1 read last and ends with what the next stage 1 reads first, which

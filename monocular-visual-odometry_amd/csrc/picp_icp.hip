@@ -386,8 +386,11 @@ int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const doub
     PICP_REQUIRE(ctx && cam && sched && state && mean_ms && min_ms && reps > 0, "picp_profile_run: bad argument");
     if (int rc = check_corr(u, v, x, y, z, M)) return rc;
     if (int rc = check_pose(w_T_c0_host)) return rc;
-    PICP_REQUIRE(M > 0 && M <= resident_capacity(ctx), "picp_profile_run: %lld correspondences do not fit the "
-                 "single-launch loop (capacity %lld)", (long long)M, (long long)resident_capacity(ctx));
+    const bool on_chip = M > 0 && M <= resident_capacity(ctx);
+    PICP_REQUIRE(on_chip || (M > 0 && ctx->resident_limit > 0 && aligned16(u) && aligned16(v) && aligned16(x) &&
+                             aligned16(y) && aligned16(z)),
+                 "picp_profile_run: %lld correspondences do not run as a single launch (on-chip capacity %lld; larger "
+                 "inputs need 16-byte aligned arrays)", (long long)M, (long long)resident_capacity(ctx));
     DeviceGuard g(ctx->device);
     hipEvent_t e0, e1;
     PICP_HIP_CHECK(hipEventCreate(&e0));
@@ -395,7 +398,8 @@ int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const doub
     double sum = 0.0, best = 1e30;
     int rc = PICP_OK;
     for (int r = 0; r < reps && rc == PICP_OK; ++r) {
-        rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, nullptr, 0, nullptr, e0, e1);
+        rc = on_chip ? enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, nullptr, 0, nullptr, e0, e1)
+                     : enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, nullptr, 0, nullptr, e0, e1);
         if (rc != PICP_OK) break;
         hipError_t e = hipEventSynchronize(e1);
         float ms = 0.f;
@@ -480,7 +484,7 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
     if (M > resident_capacity(ctx) && ctx->resident_limit > 0 && M <= ctx->persistent_limit &&
         sched->num_iterations > 0 && aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z)) {
         if (int rc = enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
-                                        ctx->pinned))
+                                        ctx->pinned, nullptr, nullptr))
             return rc;
         PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (ctx->pinned[ST_STOP] != 0.0) {

@@ -641,7 +641,8 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
 // Same completion protocol as enqueue_resident.
 int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                        const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
-                       const picp_schedule* sched, double* hist, int hist_rows, double* host_state) {
+                       const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
+                       hipEvent_t e1) {
     PICP_REQUIRE(M > 0, "persistent loop: no correspondences");
     const int64_t steps = ((M >> 1) + NTR - 1) / NTR; // workgroups needed for one grid-stride step
     const int grid = (int)(steps < 1 ? 1 : (steps > resident_grid(ctx) ? resident_grid(ctx) : steps));
@@ -656,8 +657,12 @@ int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const do
     const bool pin = is_pinhole(cam->K);
     auto kern = stage2_reverse(ctx, M) ? (pin ? icp_persistent_kernel<true, true> : icp_persistent_kernel<false, true>)
                                        : (pin ? icp_persistent_kernel<true, false> : icp_persistent_kernel<false, false>);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, u, v, x, y, z, M, state, pose, c, *sched, gx, hist,
-                       hist_rows, host_state);
+    if (e0 != nullptr)
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, pose, c,
+                              *sched, gx, hist, hist_rows, host_state);
+    else
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, u, v, x, y, z, M, state, pose, c, *sched, gx,
+                           hist, hist_rows, host_state);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
 }
