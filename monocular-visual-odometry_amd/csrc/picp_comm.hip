@@ -35,25 +35,28 @@ struct Rccl {
     GetErrorStringFn error_string = nullptr;
 };
 
-static Rccl* rccl() {
-    static Rccl lib;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        // a copy the process has already loaded (PyTorch carries one) is found by its soname
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
-            lib.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (lib.handle) break;
-        }
-        if (lib.handle) {
-            lib.get_unique_id = (GetUniqueIdFn)dlsym(lib.handle, "ncclGetUniqueId");
-            lib.comm_init_rank = (CommInitRankFn)dlsym(lib.handle, "ncclCommInitRank");
-            lib.comm_destroy = (CommDestroyFn)dlsym(lib.handle, "ncclCommDestroy");
-            lib.all_reduce = (AllReduceFn)dlsym(lib.handle, "ncclAllReduce");
-            lib.error_string = (GetErrorStringFn)dlsym(lib.handle, "ncclGetErrorString");
-        }
+static Rccl load_rccl() {
+    Rccl lib;
+    // a copy the process has already loaded (PyTorch carries one) is found by its soname
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        lib.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (lib.handle) break;
     }
+    if (lib.handle) {
+        lib.get_unique_id = (GetUniqueIdFn)dlsym(lib.handle, "ncclGetUniqueId");
+        lib.comm_init_rank = (CommInitRankFn)dlsym(lib.handle, "ncclCommInitRank");
+        lib.comm_destroy = (CommDestroyFn)dlsym(lib.handle, "ncclCommDestroy");
+        lib.all_reduce = (AllReduceFn)dlsym(lib.handle, "ncclAllReduce");
+        lib.error_string = (GetErrorStringFn)dlsym(lib.handle, "ncclGetErrorString");
+    }
+    return lib;
+}
+
+// The loaded library, or null when it (or one of the five symbols) is missing.  Loaded once per
+// process (a function-local static: safe when two threads with their own contexts get here together).
+static Rccl* rccl() {
+    static Rccl lib = load_rccl();
     const bool ok = lib.handle && lib.get_unique_id && lib.comm_init_rank && lib.comm_destroy && lib.all_reduce;
     return ok ? &lib : nullptr;
 }
