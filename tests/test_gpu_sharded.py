@@ -222,3 +222,44 @@ def test_two_ranks_association_query_rows_sharded():
         assert p.exitcode == 0
     for rank, g1, g2 in results:
         assert np.array_equal(g1, r1) and np.array_equal(g2, r2)
+
+
+@pytest.mark.parametrize("M,world", [(5, 8), (1, 2), (4099, 3), (100_001, 8)])
+def test_ragged_and_empty_shards(M, world):
+    """Shards of unequal size, some of them empty (fewer correspondences than ranks): the shards are
+    processed one after the other on the one GPU and their records added where ranks would
+    all-reduce them; counts equal the oracle's and the loop over the whole array, poses within 1e-9."""
+    ctx = pkg.get_context(0)
+    n_it = 6
+    uv, pw, _ = make_problem(M, seed=17)
+    cam, sched = _cam_sched(n_it, True)
+    corr = ctx.soa(uv, pw)
+    res, hist = ctx.run(corr, np.eye(4), cam, sched)
+    shards = []
+    for r in range(world):
+        lo, hi = pkg.sharded.shard_bounds(M, r, world)
+        shards.append(pkg.sharded.HipStages(ctx, [c[lo:hi] for c in corr], np.eye(4), cam, sched))
+    assert sum(s.M for s in shards) == M
+    for s in shards:
+        s.state_init()
+    rounds = 0
+    while not shards[0].stopped():      # a round completes an iteration, or only switches to the stage-1 set
+        rounds += 1
+        assert rounds <= 2 * n_it
+        s1 = torch.zeros(L.S1_DOUBLES, dtype=torch.float64, device=ctx.device)
+        for s in shards:
+            s1 += s.stage1()
+        s2 = torch.zeros(L.S2_DOUBLES, dtype=torch.float64, device=ctx.device)
+        for s in shards:
+            s2 += s.stage2(s1)
+        for s in shards:
+            s.solve(s1, s2)
+    outs = [s.finish() for s in shards]
+    T_ref, _, h_ref = po.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=n_it, disable_stop=True))
+    for r8, h8 in outs:
+        assert r8.num_iterations == res.num_iterations == len(h_ref["error"])
+        assert h8[:, L.H_NUM_INLIERS].astype(int).tolist() == h_ref["num_inliers"]
+        assert np.array_equal(h8[:, L.H_NUM_INLIERS], hist[:, L.H_NUM_INLIERS])
+        assert rel_err(np.array(list(r8.T)).reshape(4, 4), T_ref) < 1e-9
+    for s in shards[1:]:
+        assert np.array_equal(s.state.cpu().numpy(), shards[0].state.cpu().numpy())
