@@ -51,8 +51,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("M,num_iterations,disable_stop", [(4001, 40, False), (600, 12, True), (3, 5, False)])
-def test_two_rank_run_equals_single_process(M, num_iterations, disable_stop):
+@pytest.mark.parametrize("M,num_iterations,disable_stop,world",
+                         [(4001, 40, False, 2), (600, 12, True, 2), (3, 5, False, 2), (5, 6, True, 4)])
+def test_sharded_run_equals_single_process(M, num_iterations, disable_stop, world):
+    """Two ranks, and four ranks with fewer correspondences than ranks allow (empty shards)."""
     uv, pw, _ = make_problem(M, seed=5)
     params = po.IcpParams(num_iterations=num_iterations, disable_stop=disable_stop)
     T_ref, valid_ref, h_ref = po.projective_icp(uv, pw, np.eye(4), params)
@@ -63,7 +65,8 @@ def test_two_rank_run_equals_single_process(M, num_iterations, disable_stop):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, M, num_iterations, disable_stop, out)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, M, num_iterations, disable_stop, out))
+             for r in range(world)]
     for p in procs:
         p.start()
     results = [out.get(timeout=120) for _ in procs]
@@ -76,7 +79,8 @@ def test_two_rank_run_equals_single_process(M, num_iterations, disable_stop):
         assert thr == h_ref["kernel_threshold"]
         assert len(err) == len(h_ref["error"])
         assert rel_err(T, T_ref) < 1e-9
-    assert np.array_equal(results[0][1], results[1][1])           # replicas stay bit-identical
+    for other in results[1:]:
+        assert np.array_equal(results[0][1], other[1])            # replicas stay bit-identical
 
 
 def _assoc_rank(rank, world, port, out):
