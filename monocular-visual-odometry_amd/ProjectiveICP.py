@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from ._lib import camera_struct, get_context, schedule_struct
 from .data_association import data_association_on_appearance, match_indices
-from .two_view import essential_from_matches, recover_pose, triangulate_points
+from .two_view import find_essential_mat, recover_pose, triangulate_points
 from .geometry_utils import Rt2T
 
 
@@ -89,8 +89,8 @@ class ProjectiveICP:
         self.__update_state(w_T_c0, {'position': [], 'appearance': []}, 0.0)
 
         K = self.__camera.get_camera_matrix()
-        E, mask = essential_from_matches(points_0, points_1, K)
-        R, t, mask = recover_pose(E, points_0, points_1, K, mask)
+        E, mask = find_essential_mat(points_0, points_1, K)              # :68
+        R, t, mask = recover_pose(E, points_0, points_1, K, mask)       # :69
         c0_T_c1 = Rt2T(R, -t)                                           # :70 (note the sign)
         w_T_c1 = w_T_c0 @ c0_T_c1
 

@@ -1,6 +1,8 @@
 """Runs the bundled 121-frame sequence end to end on the GPU, like the reference's main.py with the
 shipped config/config.yaml values, and compares the result files with the reference's published
 outputs (tests/golden/bundled_sequence.npz holds both the sequence and the published files).
+The bootstrap restates cv2.findEssentialMat's deterministic RANSAC (two_view.find_essential_mat), so
+the whole run is comparable with the published one number by number.
 
     python run_sequence.py [--workdir DIR] [--final-frame N]
 """
@@ -72,6 +74,10 @@ def main(argv=None):
         "max_trajectory_position_diff": float(np.max(np.abs(np.array([p[:3, 3] for p in r["trajectory"]])
                                                             - pub_traj[:n + 1, 1:4]))),
     }
+    if len(r["world_points"]) == len(pub_pts):
+        # the map in insertion order: same points (appearance) at the same places
+        summary["map_appearances_identical"] = bool(np.array_equal(np.array(r["world_appearance"]), pub_pts[:, 4:]))
+        summary["max_world_point_diff"] = float(np.max(np.abs(np.array(r["world_points"]) - pub_pts[:, 1:4])))
     os.chdir(cwd)
     if argv is None:
         print(json.dumps(summary, indent=1))

@@ -99,6 +99,63 @@ def test_two_view_recovers_pose_and_structure():
     assert mfar.shape == (1,)
 
 
+def _frame_matches(bundled, f0, f1):
+    """Matched pixels of two frames in the reference's order (src/data_association.py:29-31)."""
+    mo, uv, app = bundled["meas_offsets"], bundled["meas_uv"], bundled["meas_app"]
+    u0, a0 = uv[mo[f0]:mo[f0 + 1]], app[mo[f0]:mo[f0 + 1]]
+    u1, a1 = uv[mo[f1]:mo[f1 + 1]], app[mo[f1]:mo[f1 + 1]]
+    i0, i1 = po.associate(a0, a1)
+    return u0[i0], u1[i1], a0[i0]
+
+
+def test_opencv_generator_and_five_point_solver():
+    rng = pkg.two_view.OpenCVRng()
+    draws = [rng.uniform(0, 115) for _ in range(5)]
+    assert draws == [100, 4, 65, 28, 16]                  # the first sample of the published run (see below)
+    assert pkg.two_view.OpenCVRng(0).state == 0xFFFFFFFF
+    # five exact correspondences of a known motion: one of the solutions is the true essential matrix
+    g = np.random.default_rng(5)
+    c0_T_c1 = po.v2T([0.3, -0.1, 0.5, 0.05, -0.08, 0.02])
+    c1_T_c0 = np.linalg.inv(c0_T_c1)
+    X0 = np.column_stack([g.uniform(-2, 2, 5), g.uniform(-2, 2, 5), g.uniform(3, 9, 5)])
+    X1 = X0 @ c1_T_c0[:3, :3].T + c1_T_c0[:3, 3]
+    sols = pkg.two_view.five_point(X0[:, :2] / X0[:, 2:3], X1[:, :2] / X1[:, 2:3])
+    tx = pkg.geometry_utils.skew(c1_T_c0[:3, 3])
+    E_true = tx @ c1_T_c0[:3, :3]
+    E_true /= np.linalg.norm(E_true)
+    assert 1 <= len(sols) <= 10
+    assert min(min(np.abs(E - E_true).max(), np.abs(E + E_true).max()) for E in sols) < 1e-6   # v2T: float32 trig
+    for E in sols:                                         # every solution is an essential matrix
+        sv = np.linalg.svd(E, compute_uv=False)
+        assert abs(sv[0] - sv[1]) < 1e-8 and sv[2] < 1e-8
+
+
+def test_bootstrap_reproduces_the_published_first_pose_and_map(bundled):
+    """The reference's published outputs pin the bootstrap: estimated_trajectory.dat row 1 holds the
+    second camera's position (scaled, in the world frame) and estimated_world_points.dat starts
+    with the points triangulated from frames 0 and 1, in insertion order.  find_essential_mat ->
+    recover_pose -> triangulate_points on the bundled frames must give them back."""
+    K = bundled["camera_matrix"].astype(np.float64)
+    C, traj, pub = bundled["cam_transform"], bundled["published_trajectory"], bundled["published_world_points"]
+    scale = traj[0, 1] / C[0, 3]                           # row 0 is the first camera at C's translation, scaled
+    assert abs(scale - np.mean(bundled["published_errors"][:, 4])) < 1e-12
+    Cinv = np.linalg.inv(C)
+    t_pub = (Cinv @ np.append(traj[1, 1:4] / scale, 1.0))[:3]
+    p0, p1, app = _frame_matches(bundled, 0, 1)
+    assert len(p0) == 115
+    E, mask = pkg.two_view.find_essential_mat(p0, p1, K)
+    assert mask.all()                                      # the first five-point sample explains every pair
+    R, t, good = pkg.two_view.recover_pose(E, p0, p1, K, mask)
+    c0_T_c1 = pkg.geometry_utils.Rt2T(R, -t)               # src/ProjectiveICP.py:70
+    assert np.abs(c0_T_c1[:3, 3] - t_pub).max() < 1e-9
+    pts, m = pkg.two_view.triangulate_points(p0, p1, np.eye(4), c0_T_c1, K)
+    n = len(pts)
+    pub_first = (Cinv @ np.column_stack([pub[:n, 1:4] / scale, np.ones(n)]).T).T[:, :3]
+    assert np.array_equal(app[m], pub[:n, 4:])             # same points kept, same order
+    assert not any(np.array_equal(pub[n, 4:], a) for a in app)   # and the next published point is not from this pair
+    assert np.abs(pts - pub_first).max() < 1e-6 * np.abs(pub_first).max()
+
+
 def test_evaluation_reproduces_published_translation_columns(bundled):
     """errors.dat columns 4-5 (translation error / ratio) depend only on positions; the published
     estimated_trajectory.dat holds them scaled by the global scale = mean ratio.  Feeding those
