@@ -295,6 +295,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        pkg.sharded.shutdown_native_exchange(ctx)
         dist.destroy_process_group()
 
 

@@ -131,6 +131,12 @@ def init_native_exchange(ctx, group=None):
     return ok
 
 
+def shutdown_native_exchange(ctx):
+    """Destroys the ctx's RCCL communicator (collective; call it on every rank before the process
+    group is torn down, not at interpreter exit)."""
+    check(ctx.lib.picp_comm_destroy(ctx.handle), "picp_comm_destroy")
+
+
 def _all_reduce_sum(t, group, through_host):
     import torch.distributed as dist
     if through_host and t.is_cuda:
