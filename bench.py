@@ -195,9 +195,11 @@ def main():
     sched = L.schedule_struct(ITERATIONS, 10, 1000, 10, 2000, 64, 1, 64, disable_stop=True)
     pose0 = np.eye(4)
 
+    plan = ctx.plan(corr, cam, sched) if world == 1 else None     # picp_run with its arguments marshalled once
+
     def step():
         if world == 1:
-            res, _ = ctx.run(corr, pose0, cam, sched, want_history=False)
+            res, _ = plan(pose0)
         else:
             stages = pkg.sharded.HipStages(ctx, corr, pose0, cam, sched, want_history=False)
             res, _ = pkg.sharded.run_sharded(stages, ITERATIONS, disable_stop=True)

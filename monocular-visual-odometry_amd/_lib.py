@@ -276,6 +276,12 @@ class Context:
         h = hist[: res.num_iterations].cpu().numpy() if want_history else None
         return res, h
 
+    def plan(self, corr, cam: CameraStruct, sched: ScheduleStruct, want_history=False):
+        """picp_run on fixed device arrays with the call's arguments marshalled once: for callers that
+        run many loops over the same correspondences (different start poses), where the few microseconds
+        of per-call argument conversion are visible next to a loop of a few hundred microseconds."""
+        return LoopPlan(self, corr, cam, sched, want_history)
+
     def run_batched(self, corr, offsets, poses0, cam: CameraStruct, sched: ScheduleStruct, want_history=False,
                     max_count=None):
         """picp_run_batched.  offsets: int64 device tensor [B+1]; poses0: device [B,16].
@@ -372,6 +378,33 @@ class Context:
         out = np.zeros(16)
         check(self.lib.picp_v2T(self.handle, a.ctypes.data_as(_P), out.ctypes.data_as(_P)), "picp_v2T")
         return out.reshape(4, 4)
+
+
+class LoopPlan:
+    """See Context.plan.  Call it with a start pose; returns (ResultStruct, history ndarray or None).
+    The ResultStruct is reused by the next call."""
+
+    def __init__(self, ctx, corr, cam, sched, want_history):
+        self.ctx = ctx
+        self._keep = (list(corr), cam, sched)                       # the arrays and structs the pointers refer to
+        self.state = ctx.empty(STATE_DOUBLES)
+        self.rows = max(int(sched.num_iterations), 1)
+        self.hist = ctx.zeros((self.rows, HIST_STRIDE)) if want_history else None
+        self.result = ResultStruct()
+        self.pose = np.zeros(16)
+        self._args = (ctx.handle, *[_P(c.data_ptr()) for c in corr], C.c_int64(int(corr[0].numel())),
+                      _P(self.pose.ctypes.data), C.byref(cam), C.byref(sched), _P(self.state.data_ptr()),
+                      _P(self.hist.data_ptr()) if want_history else _P(0), C.c_int32(self.rows if want_history else 0),
+                      C.byref(self.result))
+        self._fn = ctx.lib.picp_run
+
+    def __call__(self, w_T_c0):
+        self.pose[:] = np.asarray(w_T_c0, dtype=np.float64).reshape(16)
+        rc = self._fn(*self._args)
+        if rc != PICP_OK:
+            check(rc, "picp_run")
+        hist = self.hist[: self.result.num_iterations].cpu().numpy() if self.hist is not None else None
+        return self.result, hist
 
 
 _contexts = {}

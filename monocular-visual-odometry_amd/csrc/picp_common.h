@@ -41,6 +41,7 @@ struct picp_ctx {
     int resident_clean_grid;       // exchange slots hold sentinels for launches of up to this many workgroups
     int resident_last_grid;        // workgroups of the last launch
     int64_t persistent_limit;      // largest M the streaming single-launch loop is used for (0: never)
+    hipEvent_t loop_done;          // recorded behind a single-launch loop; the host waits for it, not for the stream
     // sharded runs (picp_comm.hip)
     void* comm;                    // RCCL communicator of this rank, or null
     int comm_rank, comm_world;

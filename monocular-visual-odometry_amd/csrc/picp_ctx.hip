@@ -69,6 +69,7 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, sizeof(double) * PINNED_DOUBLES, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemset(ctx->scratch, 0, sizeof(double) * SCR_DOUBLES);
     if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * 3 * PICP_S2_DOUBLES * ctx->num_cus);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->loop_done, hipEventDisableTiming);
     ctx->resident_limit = INT64_MAX; // i.e. whatever fits (resident_capacity)
     ctx->resident_spin_limit = 1u << 18;
     ctx->persistent_limit = INT64_MAX;
@@ -93,6 +94,7 @@ int picp_destroy(picp_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->rslots) (void)hipFree(ctx->rslots);
+    if (ctx->loop_done) (void)hipEventDestroy(ctx->loop_done);
     if (ctx->assoc_count) (void)hipFree(ctx->assoc_count);
     if (ctx->assoc_first) (void)hipFree(ctx->assoc_first);
     if (ctx->assoc_offset) (void)hipFree(ctx->assoc_offset);

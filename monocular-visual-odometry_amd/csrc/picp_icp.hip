@@ -267,6 +267,16 @@ static void result_from_state(const double* h, const double* w_T_c0_host, picp_r
     result->best_error = h[ST_BEST_ERR];
 }
 
+// Waits for a single-launch loop that has just been enqueued.  The exchange slots are restored for
+// the next loop by a small kernel enqueued behind it; the host waits for an event recorded between
+// the two, so that launch is issued while the loop runs and is not waited for.
+static int wait_for_loop(picp_ctx* ctx) {
+    PICP_HIP_CHECK(hipEventRecord(ctx->loop_done, ctx->stream));
+    resident_refill(ctx);
+    PICP_HIP_CHECK(hipEventSynchronize(ctx->loop_done)); // (polling hipEventQuery instead measured slower)
+    return PICP_OK;
+}
+
 static int check_pose(const double* T) {
     PICP_REQUIRE(T != nullptr, "null pose");
     PICP_REQUIRE(T[12] == 0.0 && T[13] == 0.0 && T[14] == 0.0 && T[15] == 1.0,
@@ -471,10 +481,9 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
         if (int rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
                                       ctx->pinned, nullptr, nullptr))
             return rc;
-        PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // the kernel left the final state in ctx->pinned
+        if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
         if (ctx->pinned[ST_STOP] != 0.0) {
             result_from_state(ctx->pinned, w_T_c0_host, result);
-            resident_refill(ctx);
             return PICP_OK;
         }
         // the launch was abandoned at a grid-wide wait (device shared with other work): start over
@@ -486,10 +495,9 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
         if (int rc = enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
                                         ctx->pinned, nullptr, nullptr))
             return rc;
-        PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
         if (ctx->pinned[ST_STOP] != 0.0) {
             result_from_state(ctx->pinned, w_T_c0_host, result);
-            resident_refill(ctx);
             return PICP_OK;
         }
         ctx->resident_aborts += 1;

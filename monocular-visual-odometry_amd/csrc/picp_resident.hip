@@ -579,9 +579,9 @@ static void fill_slots(picp_ctx* ctx, int grid) {
     hipLaunchKernelGGL(resident_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->rslots, n);
 }
 
-// After a loop has been waited for: restore the exchange slots for the next loop of up to the same
-// number of workgroups.  Only enqueued, so it overlaps whatever the host does next; work the caller
-// puts on the stream later is ordered behind it.
+// Behind a single-launch loop: restores the exchange slots for the next loop of up to the same
+// number of workgroups.  Only enqueued (stream order puts it after the loop and before whatever the
+// caller enqueues next); the host waits for an event recorded in front of it, not for this kernel.
 void resident_refill(picp_ctx* ctx) {
     if (ctx->resident_last_grid > 1) {
         fill_slots(ctx, ctx->resident_last_grid);

@@ -343,6 +343,21 @@ def test_large_loop_against_oracle(ctx, loop_path, M):
     assert rel_err(np.array(list(res2.T)).reshape(4, 4), T2) < TOL
 
 
+def test_loop_plan_equals_run(ctx):
+    """Context.plan (arguments marshalled once) gives what Context.run gives, call after call, for
+    different start poses over the same arrays."""
+    uv, pw, _ = make_problem(50_001, seed=8)
+    corr = ctx.soa(uv, pw)
+    cam, sched = bundled_cam(), yaml_sched(30)
+    plan = ctx.plan(corr, cam, sched, want_history=True)
+    for start in (np.eye(4), po.v2T([0.1, 0.0, -0.1, 0.01, 0.0, 0.02]), np.eye(4)):
+        res, hist = ctx.run(corr, start, cam, sched)
+        res_p, hist_p = plan(start)
+        assert res_p.num_iterations == res.num_iterations and res_p.best_index == res.best_index
+        assert np.array_equal(hist_p, hist)
+        assert np.array_equal(np.array(list(res_p.T)), np.array(list(res.T)))
+
+
 def test_beyond_the_on_chip_capacity_one_launch_streams(ctx):
     """Just above the on-chip capacity picp_run switches by itself to the single launch that streams
     the arrays: same counts as the oracle, poses within 1e-9, and the same as the stage launches."""
