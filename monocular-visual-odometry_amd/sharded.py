@@ -82,9 +82,14 @@ class HipStages:
                                                self.rows if self.hist is not None else 0, int(n)), "picp_sharded_rounds")
 
     @property
+    def comm_world(self):
+        """Ranks of the ctx's own RCCL communicator (0: it has none)."""
+        return int(self.ctx.lib.picp_comm_world(self.ctx.handle))
+
+    @property
     def native_exchange(self):
-        """True when the ctx's own communicator covers the exchange (or there is nothing to exchange)."""
-        return int(self.ctx.lib.picp_comm_world(self.ctx.handle)) >= 1
+        """True when `rounds` issues the exchange itself (the ctx has a communicator)."""
+        return self.comm_world >= 1
 
     def stopped(self):
         return bool(self.state[_lib.ST_STOP].item() != 0.0)
@@ -171,11 +176,13 @@ def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=
     backend is a CPU transport and is used for rehearsals on machines without one GPU per rank)."""
     import torch.distributed as dist
     exchange = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    ranks = dist.get_world_size(group) if exchange else 1
+    covered = getattr(stages, "comm_world", 0) == ranks          # the ctx's communicator spans exactly these ranks
     if native is None:
-        native = getattr(stages, "native_exchange", False) or (not exchange and hasattr(stages, "rounds"))
+        native = hasattr(stages, "rounds") and (covered or not exchange)
     if native:
-        if exchange and not getattr(stages, "native_exchange", False):
-            raise _lib.PicpError("run_sharded(native=True) needs init_native_exchange on every rank first")
+        if exchange and not covered:
+            raise _lib.PicpError("run_sharded(native=True) needs init_native_exchange over the same ranks first")
         return _run_native(stages, int(num_iterations), check_every, disable_stop)
     if through_host is None:
         through_host = exchange and dist.get_backend(group) != "nccl"
