@@ -241,14 +241,15 @@ def essential_from_matches(points_0, points_1, K, threshold=1.0, rounds=3):
 
 
 def _triangulate_normalized(P0, P1, x0, x1):
-    """Homogeneous DLT triangulation, one 4x4 null-space problem per point."""
-    X = np.empty((len(x0), 4))
-    for k in range(len(x0)):
-        A = np.stack([x0[k, 0] * P0[2] - P0[0], x0[k, 1] * P0[2] - P0[1],
-                      x1[k, 0] * P1[2] - P1[0], x1[k, 1] * P1[2] - P1[1]])
-        _, _, Vt = np.linalg.svd(A)
-        X[k] = Vt[-1]
-    return X
+    """Homogeneous DLT triangulation: per point the right singular vector of the smallest singular
+    value of the 4x4 matrix of the two views' constraints (one batched SVD)."""
+    x0 = np.asarray(x0, dtype=np.float64)
+    x1 = np.asarray(x1, dtype=np.float64)
+    if len(x0) == 0:
+        return np.zeros((0, 4))
+    A = np.stack([x0[:, 0, None] * P0[2] - P0[0], x0[:, 1, None] * P0[2] - P0[1],
+                  x1[:, 0, None] * P1[2] - P1[0], x1[:, 1, None] * P1[2] - P1[1]], axis=1)
+    return np.linalg.svd(A)[2][:, -1, :]
 
 
 def recover_pose(E, points_0, points_1, K, mask=None, distance_threshold=50.0):
