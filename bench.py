@@ -210,6 +210,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 and int(ctx.lib.picp_comm_world(ctx.handle)) == world:
+        # one guarded loop through the library's own exchange: if it fails on any rank, every rank
+        # drops its communicator and the run goes through torch.distributed's all-reduce instead
+        try:
+            step()
+            torch.cuda.synchronize()
+            ok = 1
+        except Exception as e:                                       # noqa: BLE001 - reported, then the fallback runs
+            print(f"rank {rank}: library exchange failed ({e}); falling back to torch.distributed", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            ctx.lib.picp_comm_destroy(ctx.handle)
+            collective = "rccl through torch.distributed (the library's exchange failed in its trial loop)"
     for _ in range(args.warmup):
         res = step()
     fence()
