@@ -354,7 +354,9 @@ __global__ __launch_bounds__(ANT) void project_kernel(const double* __restrict__
                                                       double* __restrict__ vv) {
     const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
     if (i >= N) return;
-    const Projected p = project_point<false>(T.m, cam, x[i], y[i], z[i]);
+    double px = x[i], py = y[i], pz = z[i];
+    homogeneous_nan(px, py, pz);
+    const Projected p = project_point<false>(T.m, cam, px, py, pz);
     inside[i] = p.inside ? 1 : 0;
     uu[i] = p.u;
     vv[i] = p.v;

@@ -81,11 +81,26 @@ __device__ __forceinline__ double div_with_recip(double a, double b, double r) {
 
 // ---- Camera.project_point (src/Camera.py:104-119) -------------------------------------------
 // T = c_T_w rows 0..2 (12 doubles).  The reference also forms the homogeneous w and divides by
-// it; every pose it builds has last row (0,0,0,1), so w == 1 exactly and the division is the
-// identity.  Order follows the reference: both pixel divisions happen before any test, then
+// it; every pose it builds has last row (0,0,0,1), so for finite points w == 1 exactly and the
+// division is the identity (non-finite points: homogeneous_nan below, applied where the points
+// are loaded).  Order follows the reference: both pixel divisions happen before any test, then
 // "z <= 0 -> outside", then the four image-bound tests.  Tests are written as negations of the
 // reference's reject conditions so that NaN behaves as in Python (a NaN coordinate rejects
 // nothing).
+// The reference's homogeneous coordinate w = 0 x + 0 y + 0 z + 1 (src/Camera.py:104-106, pose last
+// row (0, 0, 0, 1)) is NaN as soon as one coordinate is infinite or NaN (0 * inf), and the division
+// by it then turns the whole camera point into NaN, whatever the pose.  A point with all three
+// coordinates NaN goes through the transform the same way, so such points are replaced by
+// (NaN, NaN, NaN) when they are loaded; finite points are left as they are.
+__device__ __forceinline__ void homogeneous_nan(double& x, double& y, double& z) {
+#pragma clang fp contract(off)
+    const double t = __builtin_fma(0.0, z, __builtin_fma(0.0, y, 0.0 * x)); // 0 or NaN
+    const bool bad = (t != t);
+    x = bad ? t : x;
+    y = bad ? t : y;
+    z = bad ? t : z;
+}
+
 struct Projected {
     double pcx, pcy, pcz; // point in camera coordinates
     double h0, h1, h2;    // K @ pc
@@ -999,7 +1014,11 @@ struct CorrStream {
                       reinterpret_cast<const double2*>(z), head);
     }
     template <typename F>
-    __device__ __forceinline__ void run(F&& point) {
+    __device__ __forceinline__ void run(F&& visit) {
+        auto point = [&](double mu, double mv, double px, double py, double pz) {
+            homogeneous_nan(px, py, pz);
+            visit(mu, mv, px, py, pz);
+        };
         if (VEC == 2) {
             const int64_t n2 = M >> 1;
             const double2* u2 = reinterpret_cast<const double2*>(u);

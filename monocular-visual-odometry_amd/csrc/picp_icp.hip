@@ -175,8 +175,11 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
         for (int i = 0; i < 12; ++i) T[i] = st[ST_C_T_W + i];
         const double thr = st[ST_THR];
         Stage1Sums a{0.0, 0u, 0u};
-        for (int i = threadIdx.x; i < cnt; i += NT)
-            stage1_point<PINHOLE>(T, cam, thr, u[beg + i], v[beg + i], x[beg + i], y[beg + i], z[beg + i], a);
+        for (int i = threadIdx.x; i < cnt; i += NT) {
+            double px = x[beg + i], py = y[beg + i], pz = z[beg + i];
+            homogeneous_nan(px, py, pz);
+            stage1_point<PINHOLE>(T, cam, thr, u[beg + i], v[beg + i], px, py, pz, a);
+        }
         {
             const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
             const double tot = block_sum<3, NT>(vals, lds);
@@ -192,9 +195,11 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
                 const bool all = (st[ST_MODE] != 0.0);
                 Stage2Sums s;
                 s.clear();
-                for (int i = threadIdx.x; i < cnt; i += NT)
-                    stage2_point<PINHOLE>(T, cam, thr, mean, all, u[beg + i], v[beg + i], x[beg + i], y[beg + i],
-                                          z[beg + i], s);
+                for (int i = threadIdx.x; i < cnt; i += NT) {
+                    double px = x[beg + i], py = y[beg + i], pz = z[beg + i];
+                    homogeneous_nan(px, py, pz);
+                    stage2_point<PINHOLE>(T, cam, thr, mean, all, u[beg + i], v[beg + i], px, py, pz, s);
+                }
                 double vals[S2_USED];
                 pack_sets(s, vals);
                 const double tot = block_sum<S2_USED, NT>(vals, lds);

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         rx[r] = x[j];
         ry[r] = y[j];
         rz[r] = z[j];
+        homogeneous_nan(rx[r], ry[r], rz[r]);
         mine += ok ? 1 : 0;
     }
     // loop entry (src/ProjectiveICP.py:157-171): every workgroup builds its own copy of the state
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(NTB, (R <= BATCHED_THREE_PER_CU_MAX_R) ? 3 : 2) voi
         rx[r] = any ? x[j] : 0.0;
         ry[r] = any ? y[j] : 0.0;
         rz[r] = any ? z[j] : 0.0;
+        homogeneous_nan(rx[r], ry[r], rz[r]);
         mine += ok ? 1 : 0;
     }
     __syncthreads();

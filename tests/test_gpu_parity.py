@@ -343,6 +343,45 @@ def test_large_loop_against_oracle(ctx, loop_path, M):
     assert rel_err(np.array(list(res2.T)).reshape(4, 4), T2) < TOL
 
 
+def test_degenerate_points_on_every_path(ctx, loop_path):
+    """Points on and behind the camera plane, at the image border, with infinite, NaN, huge and
+    denormal coordinates or measurements, mixed into a regular problem: in-image and inlier counts as
+    the oracle's (the reference divides before it tests, src/Camera.py:104-119, so NaN passes the
+    in-image test and then fails chi <= threshold), poses within 1e-9.  (A point the reference accepts
+    with a non-finite Jacobian -- depth 5e-324 -- makes its lstsq raise; such inputs are left out.)"""
+    uv, pw, _ = make_problem(5000, seed=41)
+    big, tiny = 1e300, 5e-324
+    odd_pw = np.array([[0.0, 0.0, 0.0], [1.0, 1.0, 0.0], [0.3, -0.2, -4.0], [np.nan, 0.0, 5.0], [0.0, np.inf, 5.0],
+                       [0.0, 0.0, np.inf], [big, 0.0, big], [tiny, tiny, 1.0], [-big, big, 2.0],
+                       [0.0, 0.0, 1.0], [-16.0 / 9.0 * 3.0, 0.0, 3.0], [16.0 / 9.0 * 3.0, 0.0, 3.0],
+                       [0.0, -4.0 / 3.0 * 3.0, 3.0], [0.0, 4.0 / 3.0 * 3.0, 3.0], [np.nan, np.nan, np.nan]])
+    odd_uv = np.array([[320.0, 240.0]] * len(odd_pw))
+    odd_uv[5] = [np.nan, 240.0]
+    odd_uv[7] = [np.inf, -np.inf]
+    odd_uv[9] = [320.0 + 1e-13, 240.0]
+    where = np.linspace(3, 4990, len(odd_pw)).astype(int)
+    uv[where], pw[where] = odd_uv, odd_pw
+    params = po.IcpParams(num_iterations=5, disable_stop=True)
+    with np.errstate(all="ignore"):
+        T_ref, valid_ref, h = po.projective_icp(uv, pw, np.eye(4), params, record_linear=True)
+    res, hist = ctx.run(ctx.soa(uv, pw), np.eye(4), bundled_cam(), yaml_sched(5, disable_stop=True))
+    assert res.num_iterations == 5
+    assert np.array_equal(hist[:, L.H_N_INSIDE].astype(np.int64), np.array(h["n_inside"]))
+    assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h["num_inliers"]))
+    assert np.all(np.isfinite(hist[:, L.H_T:L.H_T + 16]))
+    assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(h["T"])) < TOL
+    assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
+    # the same points alone: nothing usable, the pose must stay where it was
+    with np.errstate(all="ignore"):
+        T2, valid2, h2 = po.projective_icp(odd_uv, odd_pw, np.eye(4), po.IcpParams(num_iterations=3, disable_stop=True),
+                                           record_linear=True)
+    res2, hist2 = ctx.run(ctx.soa(odd_uv, odd_pw), np.eye(4), bundled_cam(), yaml_sched(3, disable_stop=True))
+    assert np.array_equal(hist2[:, L.H_N_INSIDE].astype(np.int64), np.array(h2["n_inside"]))
+    assert np.array_equal(hist2[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h2["num_inliers"]))
+    assert bool(res2.valid) == valid2
+    assert rel_err(np.array(list(res2.T)).reshape(4, 4), T2) < TOL
+
+
 def test_loop_plan_equals_run(ctx):
     """Context.plan (arguments marshalled once) gives what Context.run gives, call after call, for
     different start poses over the same arrays."""
