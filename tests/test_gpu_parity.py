@@ -343,6 +343,28 @@ def test_large_loop_against_oracle(ctx, loop_path, M):
     assert rel_err(np.array(list(res2.T)).reshape(4, 4), T2) < TOL
 
 
+def test_no_correspondences_and_no_iterations(ctx, loop_path):
+    """M = 0 (src/ProjectiveICP.py:263: no step is computed, the loop still runs its schedules)
+    against the oracle, and num_iterations = 0."""
+    cam = bundled_cam()
+    start = po.v2T([0.1, -0.2, 0.3, 0.01, 0.02, -0.03])
+    empty = ctx.soa(np.zeros((0, 2)), np.zeros((0, 3)))
+    T_ref, valid_ref, h = po.projective_icp(np.zeros((0, 2)), np.zeros((0, 3)), start, po.IcpParams(num_iterations=7),
+                                            record_linear=True)
+    res, hist = ctx.run(empty, start, cam, yaml_sched(7))
+    assert res.num_iterations == len(h["error"]) and bool(res.valid) == valid_ref
+    assert np.array_equal(hist[:, L.H_KERNEL_THR], np.array(h["kernel_threshold"], dtype=np.float64))
+    assert np.array_equal(hist[:, L.H_DAMPING], np.array(h["dumping_factor"], dtype=np.float64))
+    assert np.all(np.isinf(hist[:, L.H_ERROR])) and np.all(hist[:, L.H_NUM_INLIERS] == 0)
+    assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
+    # num_iterations = 0: the reference raises there (np.argmin of an empty list, :249); the library
+    # reports an invalid result and hands the start pose back
+    uv, pw, _ = make_problem(300, seed=2)
+    res0, hist0 = ctx.run(ctx.soa(uv, pw), start, cam, yaml_sched(0))
+    assert res0.num_iterations == 0 and hist0.shape[0] == 0 and not res0.valid
+    assert np.array_equal(np.array(list(res0.T)).reshape(4, 4), start)
+
+
 def test_degenerate_points_on_every_path(ctx, loop_path):
     """Points on and behind the camera plane, at the image border, with infinite, NaN, huge and
     denormal coordinates or measurements, mixed into a regular problem: in-image and inlier counts as
