@@ -315,6 +315,27 @@ def test_association_signed_zero_and_nan(ctx, assoc_mode):
     assert r1.tolist() == [0, 1, 3, 4] and r2.tolist() == [10, 11, 13, 10]
 
 
+def test_association_random_collisions(ctx, assoc_mode):
+    """Descriptors drawn from a handful of values (zeros of both signs, infinities, NaN, a denormal)
+    in widths 1 .. 13, so that equal rows, rows equal up to the sign of a zero and rows that differ
+    only in their last component abound: pair lists identical to the reference's double loop
+    (float ==: -0.0 equals 0.0, NaN equals nothing; src/data_association.py:29-31)."""
+    rng = np.random.default_rng(99)
+    values = np.array([0.0, -0.0, 1.0, -1.0, 0.5, np.inf, -np.inf, np.nan, 1e-310, 2.0 ** -1074])
+    for k in range(60):
+        D = int(rng.choice([1, 2, 3, 5, 10, 13]))
+        n1, n2 = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        weights = np.array([4, 4, 3, 2, 2, 1, 1, 0.3 if D > 2 else 1, 1, 1], dtype=np.float64)
+        app1 = rng.choice(values, size=(n1, D), p=weights / weights.sum())
+        app2 = rng.choice(values, size=(n2, D), p=weights / weights.sum())
+        if D >= 5:                                    # long equal prefixes, differences late in the row
+            app2[:, :D - 2] = app2[0, :D - 2]
+            app1[:, :D - 2] = app2[0, :D - 2]
+        r1, r2 = po.associate(app1, app2)
+        i1, i2 = ctx.associate(ctx.to_device(app1), ctx.to_device(app2))
+        assert np.array_equal(i1.cpu().numpy(), r1) and np.array_equal(i2.cpu().numpy(), r2), (k, D, n1, n2)
+
+
 @pytest.mark.parametrize("M", [1 << 21, 1_500_001, 1 << 20, 700_001, 300_001, 70_000])
 def test_large_loop_against_oracle(ctx, loop_path, M):
     """Up to 2^21 correspondences, 6 iterations: counts exact, H/b/T within 1e-9 of the numpy oracle.
@@ -393,6 +414,20 @@ def test_degenerate_points_on_every_path(ctx, loop_path):
     assert np.all(np.isfinite(hist[:, L.H_T:L.H_T + 16]))
     assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(h["T"])) < TOL
     assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
+    if loop_path == "streaming":        # the two batched kernels (they do not depend on picp_run's path)
+        corr = ctx.soa(uv, pw)
+        for max_count in (len(uv), 0):      # held on chip (16 per thread would not fit 5 000: re-read) / re-read
+            results, hb = ctx.run_batched(corr, ctx.to_device(np.array([0, 4000, len(uv)]), np.int64),
+                                          ctx.to_device(np.tile(np.eye(4).reshape(1, 16), (2, 1))), bundled_cam(),
+                                          yaml_sched(5, disable_stop=True), want_history=True,
+                                          max_count=min(max_count, 4000))
+            hb = hb.cpu().numpy()
+            for p, (a, b) in enumerate(((0, 4000), (4000, len(uv)))):
+                with np.errstate(all="ignore"):
+                    _, _, hp = po.projective_icp(uv[a:b], pw[a:b], np.eye(4), params, record_linear=True)
+                assert np.array_equal(hb[p, :5, L.H_N_INSIDE].astype(np.int64), np.array(hp["n_inside"])), (max_count, p)
+                assert np.array_equal(hb[p, :5, L.H_NUM_INLIERS].astype(np.int64), np.array(hp["num_inliers"]))
+                assert rel_err(hb[p, :5, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(hp["T"])) < TOL
     # the same points alone: nothing usable, the pose must stay where it was
     with np.errstate(all="ignore"):
         T2, valid2, h2 = po.projective_icp(odd_uv, odd_pw, np.eye(4), po.IcpParams(num_iterations=3, disable_stop=True),
