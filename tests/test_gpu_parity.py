@@ -364,6 +364,27 @@ def test_large_loop_against_oracle(ctx, loop_path, M):
     assert rel_err(np.array(list(res2.T)).reshape(4, 4), T2) < TOL
 
 
+def test_projection_of_degenerate_points(ctx):
+    """Camera.project_point (src/Camera.py:82-121) on points at, behind and beside the camera and with
+    non-finite coordinates, under a rotated pose: the in-image flags of the oracle, pixels equal
+    where they are finite."""
+    big, tiny = 1e300, 5e-324
+    pts = np.array([[0.0, 0.0, 0.0], [1.0, 1.0, 0.0], [0.3, -0.2, -4.0], [np.nan, 0.0, 5.0], [0.0, np.inf, 5.0],
+                    [0.0, 0.0, np.inf], [-np.inf, 0.0, 1.0], [big, 0.0, big], [tiny, tiny, 1.0], [-big, big, 2.0],
+                    [0.0, 0.0, tiny], [0.0, 0.0, 1.0], [-5.0, 0.0, 3.0], [5.4, 0.0, 3.0], [0.1, -4.1, 3.0],
+                    [np.nan, np.nan, np.nan], [1.0, 2.0, 30.0], [-3.0, 1.0, 7.5]])
+    for pose in (np.eye(4), po.v2T([0.04, -0.03, 0.18, 0.3, -0.2, 0.15])):
+        c_T_w = np.linalg.inv(pose)
+        with np.errstate(all="ignore"):
+            inside_ref, uv_ref, _ = po.project_points(c_T_w, po.IcpParams(), pts)
+        inside, u, v = ctx.project(ctx.to_device(np.ascontiguousarray(pts.T)), c_T_w, bundled_cam())
+        assert np.array_equal(inside.cpu().numpy().astype(bool), inside_ref)
+        uv = np.stack([u.cpu().numpy(), v.cpu().numpy()], axis=1)
+        ok = np.isfinite(uv_ref).all(axis=1)
+        assert np.array_equal(np.isfinite(uv).all(axis=1), ok)
+        assert np.allclose(uv[ok], uv_ref[ok], rtol=1e-12, atol=0)
+
+
 def test_no_correspondences_and_no_iterations(ctx, loop_path):
     """M = 0 (src/ProjectiveICP.py:263: no step is computed, the loop still runs its schedules)
     against the oracle, and num_iterations = 0."""
