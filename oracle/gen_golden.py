@@ -397,6 +397,49 @@ def gen_general_camera(ref_picp_mod, Camera, Data, geo):
         os.chdir(back)
 
 
+
+# --------------------------------------------------------------------------
+# 7. degenerate points (non-finite coordinates, camera plane, behind the camera)
+# --------------------------------------------------------------------------
+
+
+def gen_degenerate(ref_picp_mod, cam, data, geo):
+    """A regular synthetic problem with points on and behind the camera plane and with infinite, NaN
+    and huge coordinates or measurements mixed in, from a rotated start pose: pins what the
+    reference's homogeneous division and its comparisons do with them (src/Camera.py:104-119)."""
+    rng = np.random.default_rng(41)
+    M = 3000
+    uv, pw = synth_problem(rng, M, geo)
+    big, tiny = 1e300, 5e-324
+    odd_pw = np.array([[0.0, 0.0, 0.0], [1.0, 1.0, 0.0], [0.3, -0.2, -4.0], [np.nan, 0.0, 5.0], [0.0, np.inf, 5.0],
+                       [0.0, 0.0, np.inf], [big, 0.0, big], [tiny, tiny, 1.0], [-big, big, 2.0], [-np.inf, 1.0, 1.0],
+                       [0.0, 0.0, 1.0], [np.nan, np.nan, np.nan]])
+    odd_uv = np.array([[320.0, 240.0]] * len(odd_pw))
+    odd_uv[5] = [np.nan, 240.0]
+    odd_uv[7] = [np.inf, -np.inf]
+    where = np.linspace(3, M - 10, len(odd_pw)).astype(int)
+    uv[where], pw[where] = odd_uv, odd_pw
+    out = {"uv": uv, "pw": pw, "where": where}
+    starts = [np.eye(4), geo.v2T([0.02, -0.01, 0.05, 0.02, -0.03, 0.01]), geo.v2T([0.3, 0.2, -0.4, 0.3, -0.2, 0.15])]
+    app = rng.uniform(-1, 1, (M, 10))
+    meas = {"position": [list(p) for p in uv], "appearance": [list(a) for a in app]}
+    with np.errstate(all="ignore"):
+        for li, pose in enumerate(starts):
+            lp = make_picp(ref_picp_mod, cam, data, num_iterations=12)
+            m = lp.get_map()
+            m["position"] = [p for p in pw]
+            m["appearance"] = [list(a) for a in app]
+            m["error"] = [0.0] * M
+            r = run_icp_capture(ref_picp_mod, lp, cam, pose, meas, 0)
+            out[f"loop{li}_pose"] = pose
+            out.update({f"loop{li}_{k}": v for k, v in r.items()})
+    out["n_loops"] = len(starts)
+    out["num_iterations"] = 12
+    np.savez_compressed(os.path.join(OUT, "ref_degenerate.npz"), **out)
+    print("degenerate: loops", len(starts), "iterations", [len(out[f"loop{li}_error"]) for li in range(len(starts))],
+          "n_inside", [out[f"loop{li}_n_inside"].tolist() for li in range(len(starts))])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_picp_mod, Camera, Data, ref_da, ref_geo = import_reference()
@@ -404,12 +447,16 @@ def main():
         gen_general_camera(ref_picp_mod, Camera, Data, ref_geo)
         return
     cam, data = Camera(), Data()
+    if "--only-degenerate" in sys.argv:
+        gen_degenerate(ref_picp_mod, cam, data, ref_geo)
+        return
     pack_bundled(cam, data)
     gen_v2T(ref_geo)
     gen_association(ref_da, cam)
     gen_synthetic(ref_picp_mod, cam, data, ref_geo)
     gen_gtmap(ref_picp_mod, cam, data)
     gen_general_camera(ref_picp_mod, Camera, Data, ref_geo)
+    gen_degenerate(ref_picp_mod, Camera(), Data(), ref_geo)
 
 
 if __name__ == "__main__":

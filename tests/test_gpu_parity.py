@@ -212,6 +212,37 @@ def _gtmap_problems(bundled, g):
     return uvs, pws
 
 
+@pytest.mark.parametrize("path", ["run", "batched_on_chip", "batched_reread"])
+def test_full_loop_degenerate_points_reference(ctx, path, loop_path):
+    """Vectors of the reference itself on a problem with points on and behind the camera plane and with
+    infinite, NaN and huge coordinates or measurements mixed in (three start poses, 12 iterations)."""
+    if path != "run" and loop_path != "streaming":
+        pytest.skip("the batched kernels do not depend on picp_run's path")
+    g = load_golden("ref_degenerate.npz")
+    cam = bundled_cam()
+    corr = ctx.soa(g["uv"], g["pw"])
+    M = len(g["uv"])
+    sched = yaml_sched(int(g["num_iterations"]))
+    for li in range(int(g["n_loops"])):
+        pre = f"loop{li}_"
+        if path == "run":
+            res, hist = ctx.run(corr, g[f"{pre}pose"], cam, sched)
+            T, valid, best = np.array(list(res.T)).reshape(4, 4), bool(res.valid), res.best_index
+        else:
+            results, h = ctx.run_batched(corr, ctx.to_device(np.array([0, M]), np.int64),
+                                         ctx.to_device(g[f"{pre}pose"].reshape(1, 16)), cam, sched, want_history=True,
+                                         max_count=None if path == "batched_on_chip" else 0)
+            r = ctx.decode_results(results.cpu().numpy())
+            hist = h[0, : r["num_iterations"][0]].cpu().numpy()
+            T, valid, best = r["T"][0], bool(r["valid"][0]), int(r["best_index"][0])
+        check_history(hist, g, pre)
+        assert valid == bool(g[f"{pre}valid"])
+        if valid:
+            check_best(T, best, g[f"{pre}error"], g[f"{pre}T"], g[f"{pre}T_out"])
+        else:
+            assert rel_err(T, g[f"{pre}T_out"]) < TOL
+
+
 def test_gtmap_icp_120_frames_kernel_path(ctx, bundled, loop_path):
     """The reference loop's 1 574 iterations on the bundled measurements (ground-truth map) through
     picp_run: stage-1 / stage-2 / solve kernels per iteration, or the single-launch loop."""

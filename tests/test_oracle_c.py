@@ -71,6 +71,17 @@ def test_full_loops(name):
         _check_result(T, valid, best, g[f"{pre}error"], g[f"{pre}T"], g[f"{pre}T_out"])
 
 
+def test_full_loops_degenerate_points():
+    g = load_golden("ref_degenerate.npz")
+    for li in range(int(g["n_loops"])):
+        pre = f"loop{li}_"
+        params = po.IcpParams(num_iterations=int(g["num_iterations"]))
+        T, valid, rows, best = oc.projective_icp(g["uv"], g["pw"], g[f"{pre}pose"], params)
+        _check_rows(rows, g, pre)
+        assert valid == bool(g[f"{pre}valid"])
+        _check_result(T, valid, best, g[f"{pre}error"], g[f"{pre}T"], g[f"{pre}T_out"])
+
+
 def test_gtmap_icp_all_120_frames(bundled):
     """The reference's 1 574 iterations on the bundled measurements with the ground-truth map."""
     g = load_golden("ref_gtmap_icp.npz")
@@ -96,3 +107,29 @@ def test_agrees_with_the_numpy_restatement_on_a_large_problem():
     assert rows[:, oc.H_N_INSIDE].astype(int).tolist() == h2["n_inside"]
     assert rel_err(rows[:, oc.H_T:oc.H_T + 16].reshape(-1, 4, 4), np.array(h2["T"])) < TOL
     assert rel_err(T, T2) < TOL
+
+
+def test_agrees_with_the_numpy_restatement_on_degenerate_points():
+    """Points on and behind the camera plane and with non-finite coordinates or measurements inside a
+    regular problem, from a rotated start pose: the reference's homogeneous division makes a point with
+    an infinite or NaN coordinate all-NaN (src/Camera.py:104-106), which passes the in-image test and
+    fails chi <= threshold; both restatements must count alike."""
+    uv, pw, _ = make_problem(3000, seed=41)
+    big, tiny = 1e300, 5e-324
+    odd_pw = np.array([[0.0, 0.0, 0.0], [1.0, 1.0, 0.0], [0.3, -0.2, -4.0], [np.nan, 0.0, 5.0], [0.0, np.inf, 5.0],
+                       [0.0, 0.0, np.inf], [big, 0.0, big], [tiny, tiny, 1.0], [-big, big, 2.0], [-np.inf, 1.0, 1.0],
+                       [0.0, 0.0, 1.0], [np.nan, np.nan, np.nan]])
+    odd_uv = np.array([[320.0, 240.0]] * len(odd_pw))
+    odd_uv[5] = [np.nan, 240.0]
+    odd_uv[7] = [np.inf, -np.inf]
+    where = np.linspace(3, 2990, len(odd_pw)).astype(int)
+    uv[where], pw[where] = odd_uv, odd_pw
+    start = po.v2T([0.02, -0.01, 0.05, 0.02, -0.03, 0.01])
+    params = po.IcpParams(num_iterations=5, disable_stop=True)
+    with np.errstate(all="ignore"):
+        T2, valid2, h2 = po.projective_icp(uv, pw, start, params, record_linear=True)
+    T, valid, rows, best = oc.projective_icp(uv, pw, start, params)
+    assert valid == valid2
+    assert rows[:, oc.H_N_INSIDE].astype(int).tolist() == h2["n_inside"]
+    assert rows[:, oc.H_NUM_INLIERS].astype(int).tolist() == h2["num_inliers"]
+    assert rel_err(rows[:, oc.H_T:oc.H_T + 16].reshape(-1, 4, 4), np.array(h2["T"])) < TOL

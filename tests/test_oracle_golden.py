@@ -110,6 +110,20 @@ def test_full_loop_general_camera_matrix():
         assert rel_err(T, g[f"{pre}T_out"]) < TOL
 
 
+def test_full_loop_degenerate_points():
+    """The reference on a problem with points on and behind the camera plane and with infinite, NaN
+    and huge coordinates or measurements mixed in, from three start poses (12 iterations each)."""
+    g = load_golden("ref_degenerate.npz")
+    for li in range(int(g["n_loops"])):
+        pre = f"loop{li}_"
+        params = po.IcpParams(num_iterations=int(g["num_iterations"]))
+        with np.errstate(all="ignore"):
+            T, valid, hist = po.projective_icp(g["uv"], g["pw"], g[f"{pre}pose"], params, record_linear=True)
+        _check_loop(hist, T, valid, g, pre)
+        assert valid == bool(g[f"{pre}valid"])
+        assert rel_err(T, g[f"{pre}T_out"]) < TOL
+
+
 def test_gtmap_icp_all_120_frames(bundled):
     """The reference's LM loop on the bundled measurements with the ground-truth map: 1 574 iterations
     over 120 frame pairs, covering zero-inlier iterations and every schedule branch."""
