@@ -130,6 +130,32 @@ def test_opencv_generator_and_five_point_solver():
         assert abs(sv[0] - sv[1]) < 1e-8 and sv[2] < 1e-8
 
 
+def test_find_essential_mat_with_outliers():
+    """Random sampling at work: 30 % of the matches are wrong, pixels carry 0.3 px of noise; the
+    RANSAC must end with (almost) exactly the true inliers and a pose close to the true one, and the
+    call is deterministic (the generator is seeded anew per call)."""
+    rng = np.random.default_rng(17)
+    K = np.array([[180.0, 0, 320], [0, 180.0, 240], [0, 0, 1]])
+    c0_T_c1 = po.v2T([0.4, -0.1, 0.2, 0.03, 0.08, -0.02])
+    c1_T_c0 = np.linalg.inv(c0_T_c1)
+    n = 150
+    z = rng.uniform(2, 12, n)
+    X0 = np.stack([rng.uniform(-1.2, 1.2, n) * z, rng.uniform(-0.9, 0.9, n) * z, z], axis=1)
+    X1 = X0 @ c1_T_c0[:3, :3].T + c1_T_c0[:3, 3]
+    p0 = (X0 @ K.T)[:, :2] / X0[:, 2:3] + rng.normal(0, 0.3, (n, 2))
+    p1 = (X1 @ K.T)[:, :2] / X1[:, 2:3] + rng.normal(0, 0.3, (n, 2))
+    wrong = rng.random(n) < 0.3
+    p1[wrong] = np.column_stack([rng.uniform(0, 640, wrong.sum()), rng.uniform(0, 480, wrong.sum())])
+    E, mask = pkg.two_view.find_essential_mat(p0, p1, K)
+    assert mask[~wrong].mean() > 0.85 and mask[wrong].mean() < 0.15
+    R, t, good = pkg.two_view.recover_pose(E, p0, p1, K, mask)
+    t_true = c1_T_c0[:3, 3] / np.linalg.norm(c1_T_c0[:3, 3])
+    assert np.degrees(np.arccos(np.clip((np.trace(R.T @ c1_T_c0[:3, :3]) - 1) / 2, -1, 1))) < 1.0
+    assert np.degrees(np.arccos(np.clip(t[:, 0] @ t_true, -1, 1))) < 5.0
+    E2, mask2 = pkg.two_view.find_essential_mat(p0, p1, K)
+    assert np.array_equal(E, E2) and np.array_equal(mask, mask2)
+
+
 def test_bootstrap_reproduces_the_published_first_pose_and_map(bundled):
     """The reference's published outputs pin the bootstrap: estimated_trajectory.dat row 1 holds the
     second camera's position (scaled, in the world frame) and estimated_world_points.dat starts
