@@ -587,6 +587,40 @@ def test_projective_icp_class_on_bundled_frames(ctx, bundled, tmp_path, monkeypa
         assert rel_err(cam.get_c_T_w(), np.linalg.inv(T)) < 1e-14
 
 
+def test_class_rejects_a_frame_like_the_reference(ctx, bundled, tmp_path, monkeypatch):
+    """A map that does not fit the measurements: the loop's best error stays above 5, the frame is
+    declared invalid (src/ProjectiveICP.py:249-251), update() returns False without touching the
+    trajectory or the map, and the camera is put back on the current pose."""
+    from tests.bundled import write_data_dir
+    write_data_dir(str(tmp_path / "data"))
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("ref_gtmap_icp.npz")
+    cam, data = pkg.Camera.Camera(), pkg.Data.Data()
+    picp = pkg.ProjectiveICP.ProjectiveICP(cam, data, 40, 10, 1000, 10, 2000, 64, 1, 64, False, False, False, [])
+    rng = np.random.default_rng(1)
+    m = picp.get_map()
+    m["position"] = [p for p in rng.uniform(-3, 3, g["map_position"].shape) + np.array([0, 0, 6.0])]   # scrambled map
+    m["appearance"] = [list(a) for a in g["map_appearance"]]
+    m["error"] = [0.0] * len(m["position"])
+    pose = g["start_pose"][5].copy()
+    picp._ProjectiveICP__current_pose = pose
+    picp._ProjectiveICP__trajectory.append(pose)
+    cam.set_c_T_w(np.linalg.inv(pose))
+    n_map = len(m["position"])
+    meas = data.get_measurements_data(6)
+    uv = np.array(meas["position"])
+    i1, i2 = po.associate(np.array(meas["appearance"]), np.array(m["appearance"]))
+    T_ref, valid_ref, h_ref = po.projective_icp(uv[i1], np.array(m["position"])[i2], pose, po.IcpParams(num_iterations=40))
+    assert not valid_ref and min(h_ref["error"]) > 5
+    assert picp.update(5) is False
+    assert len(picp.get_trajectory()) == 1 and len(picp.get_map()["position"]) == n_map
+    assert np.array_equal(picp.get_current_pose(), pose)
+    assert rel_err(cam.get_c_T_w(), np.linalg.inv(pose)) < 1e-14
+    T, valid, res = picp.projective_icp(meas, 5)
+    assert not valid and np.array_equal(T, pose)
+    assert res["num_inliers"] == h_ref["num_inliers"]
+
+
 @pytest.mark.parametrize("limit", [None, 1])
 def test_single_launch_loop_gives_up_cleanly(monkeypatch, limit):
     """With a wait bound of zero polls the single-launch loop abandons its launch as soon as one record
