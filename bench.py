@@ -225,12 +225,30 @@ def main():
         if int(flag.item()) == 0:
             ctx.lib.picp_comm_destroy(ctx.handle)
             collective = "rccl through torch.distributed (the library's exchange failed in its trial loop)"
-    for _ in range(args.warmup):
-        res = step()
+    def run_steps(n):
+        """n steps.  On one GPU the loops are independent of each other, so two are kept in flight
+        (picp_run_enqueue / picp_run_collect): the host enqueues the next loop while the current one
+        runs instead of waiting in between.  Every loop's result is collected and checked."""
+        last = None
+        if world > 1 or n == 0 or os.environ.get("PICP_BENCH_PIPELINE", "1") == "0":
+            for _ in range(n):
+                last = step()
+            return last
+        depth = 2
+        for k in range(n):
+            plan.enqueue(pose0, k % depth)
+            if k >= depth - 1:
+                last = plan.collect((k - depth + 1) % depth)
+                assert last.num_iterations == ITERATIONS, last.num_iterations
+        for k in range(max(n - depth + 1, 0), n):
+            last = plan.collect(k % depth)
+            assert last.num_iterations == ITERATIONS, last.num_iterations
+        return last
+
+    res = run_steps(args.warmup) or step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = run_steps(args.steps) or res
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -295,6 +313,7 @@ def main():
                                     f"synthetic single-pose projective ICP, {M} correspondences sharded over "
                                     f"{world} GPU(s), 20 LM iterations, 2 all-reduces per iteration"),
                        "correspondences": M, "lm_iterations": ITERATIONS,
+                       "steps_in_flight": 2 if (world == 1 and os.environ.get("PICP_BENCH_PIPELINE", "1") != "0") else 1,
                        "device_path": ("single launch, register-resident" if resident else
                                        "single launch, arrays streamed twice per iteration" if world == 1 else
                                        "streaming stage launches"),

@@ -38,6 +38,7 @@ extern "C" {
 #define PICP_ERR_CAPACITY (-3)  /* an output buffer is too small; the needed size is reported */
 #define PICP_ERR_NO_DEVICE (-4) /* no usable gfx950 device */
 #define PICP_ERR_COMM (-5)      /* RCCL could not be loaded, or one of its calls failed */
+#define PICP_ERR_RETRY (-6)     /* an enqueued loop gave up on a shared device: run it again with picp_run */
 
 /* Doubles per row of the per-iteration history and of the device state block. */
 #define PICP_HIST_STRIDE 80
@@ -142,6 +143,22 @@ int picp_resident_aborts(picp_ctx* ctx);
 int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
                      const picp_schedule* sched, double* state, int32_t reps, double* mean_ms, double* min_ms);
+
+/* picp_run in two halves, for callers that keep several independent loops in flight (the host then
+ * prepares and enqueues the next loop while the current one runs, instead of waiting in between).
+ * picp_run_enqueue takes picp_run's arguments plus a slot number 0 .. PICP_ASYNC_SLOTS-1 and only
+ * enqueues; it accepts what picp_run executes as a single launch (non-empty input within
+ * picp_resident_capacity, or larger 16-byte aligned arrays; at least one iteration) and refuses
+ * everything else with PICP_ERR_INVALID.  picp_run_collect waits for the loop of that slot and fills
+ * `result` as picp_run does; PICP_ERR_RETRY means the launch gave up at an exchange (shared device)
+ * and the caller should run that loop again with picp_run.  state and hist must stay untouched until
+ * the slot has been collected, and a slot must be collected before it is used again.  Loops on one
+ * ctx execute in the order they were enqueued. */
+#define PICP_ASYNC_SLOTS 4
+int picp_run_enqueue(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                     const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
+                     const picp_schedule* sched, double* state, double* hist, int32_t hist_rows, int32_t slot);
+int picp_run_collect(picp_ctx* ctx, int32_t slot, const double* w_T_c0_host, picp_result* result);
 
 /* Same loop for B independent problems in one launch, one workgroup per problem, the whole loop
  * inside the kernel.  Problem p owns correspondences [offsets[p], offsets[p+1]).

@@ -30,6 +30,8 @@ ST_W_T_C, ST_C_T_W, ST_THR, ST_LAMBDA, ST_IT, ST_STOP = 0, 16, 32, 33, 39, 40
 PICP_OK = 0
 PICP_ERR_CAPACITY = -3
 PICP_ERR_COMM = -5
+PICP_ERR_RETRY = -6
+ASYNC_SLOTS = 4
 COMM_ID_BYTES = 128
 
 
@@ -67,6 +69,9 @@ _SIGNATURES = {
     "picp_synchronize": (C.c_int, [_P]),
     "picp_run": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
                            C.POINTER(ScheduleStruct), _P, _P, C.c_int32, C.POINTER(ResultStruct)]),
+    "picp_run_enqueue": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
+                                   C.POINTER(ScheduleStruct), _P, _P, C.c_int32, C.c_int32]),
+    "picp_run_collect": (C.c_int, [_P, C.c_int32, _P, C.POINTER(ResultStruct)]),
     "picp_set_resident_limit": (C.c_int, [_P, C.c_int64]),
     "picp_resident_capacity": (C.c_int64, [_P]),
     "picp_resident_aborts": (C.c_int, [_P]),
@@ -405,6 +410,34 @@ class LoopPlan:
             check(rc, "picp_run")
         hist = self.hist[: self.result.num_iterations].cpu().numpy() if self.hist is not None else None
         return self.result, hist
+
+    # Several loops in flight: enqueue(pose, slot) only enqueues, collect(slot) waits for that loop.
+    # Each slot has its own state block, start pose and result; no per-iteration history in this mode.
+    def enqueue(self, w_T_c0, slot):
+        if not hasattr(self, "_slots"):
+            self._slots = {}
+        if slot not in self._slots:
+            corr, cam, sched = self._keep
+            state, pose, res = self.ctx.empty(STATE_DOUBLES), np.zeros(16), ResultStruct()
+            args = (self.ctx.handle, *[_P(c.data_ptr()) for c in corr], C.c_int64(int(corr[0].numel())),
+                    _P(pose.ctypes.data), C.byref(cam), C.byref(sched), _P(state.data_ptr()), _P(0), C.c_int32(0),
+                    C.c_int32(slot))
+            self._slots[slot] = (state, pose, res, args)
+        state, pose, res, args = self._slots[slot]
+        pose[:] = np.asarray(w_T_c0, dtype=np.float64).reshape(16)
+        rc = self.ctx.lib.picp_run_enqueue(*args)
+        if rc != PICP_OK:
+            check(rc, "picp_run_enqueue")
+
+    def collect(self, slot):
+        state, pose, res, args = self._slots[slot]
+        rc = self.ctx.lib.picp_run_collect(self.ctx.handle, slot, pose.ctypes.data, C.byref(res))
+        if rc == PICP_ERR_RETRY:                      # the launch gave up on a shared device: run it synchronously
+            corr, cam, sched = self._keep
+            return self.ctx.run(corr, pose.reshape(4, 4), cam, sched, want_history=False)[0]
+        if rc != PICP_OK:
+            check(rc, "picp_run_collect")
+        return res
 
 
 _contexts = {}

@@ -42,6 +42,7 @@ struct picp_ctx {
     int resident_last_grid;        // workgroups of the last launch
     int64_t persistent_limit;      // largest M the streaming single-launch loop is used for (0: never)
     hipEvent_t loop_done;          // recorded behind a single-launch loop; the host waits for it, not for the stream
+    hipEvent_t slot_done[PICP_ASYNC_SLOTS]; // the same for loops enqueued with picp_run_enqueue, one per slot
     // sharded runs (picp_comm.hip)
     void* comm;                    // RCCL communicator of this rank, or null
     int comm_rank, comm_world;
@@ -57,7 +58,7 @@ enum : int {
     SCR_MISC = 256,                             // 64 doubles for tiny test kernels
     SCR_DOUBLES = 512,
 };
-enum : int { PINNED_DOUBLES = 4096 };
+enum : int { PINNED_DOUBLES = 4096, PINNED_SLOT0 = 2048, PINNED_SLOT_STRIDE = 128 }; // final states of enqueued loops
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);

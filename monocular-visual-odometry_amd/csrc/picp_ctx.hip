@@ -70,6 +70,8 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     if (e == hipSuccess) e = hipMemset(ctx->scratch, 0, sizeof(double) * SCR_DOUBLES);
     if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * 3 * PICP_S2_DOUBLES * ctx->num_cus);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->loop_done, hipEventDisableTiming);
+    for (int k = 0; k < PICP_ASYNC_SLOTS && e == hipSuccess; ++k)
+        e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
     ctx->resident_limit = INT64_MAX; // i.e. whatever fits (resident_capacity)
     ctx->resident_spin_limit = 1u << 18;
     ctx->persistent_limit = INT64_MAX;
@@ -95,6 +97,8 @@ int picp_destroy(picp_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->rslots) (void)hipFree(ctx->rslots);
     if (ctx->loop_done) (void)hipEventDestroy(ctx->loop_done);
+    for (int k = 0; k < PICP_ASYNC_SLOTS; ++k)
+        if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
     if (ctx->assoc_count) (void)hipFree(ctx->assoc_count);
     if (ctx->assoc_first) (void)hipFree(ctx->assoc_first);
     if (ctx->assoc_offset) (void)hipFree(ctx->assoc_offset);

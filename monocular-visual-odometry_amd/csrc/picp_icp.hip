@@ -551,6 +551,50 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
     return picp_finish(ctx, state, hist, hist_rows, w_T_c0_host, result);
 }
 
+int picp_run_enqueue(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
+                     int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched,
+                     double* state, double* hist, int32_t hist_rows, int32_t slot) {
+    PICP_REQUIRE(ctx && cam && sched && state, "picp_run_enqueue: null argument");
+    PICP_REQUIRE(slot >= 0 && slot < PICP_ASYNC_SLOTS, "picp_run_enqueue: slot %d is not in 0..%d", (int)slot,
+                 PICP_ASYNC_SLOTS - 1);
+    PICP_REQUIRE(sched->num_iterations > 0, "picp_run_enqueue: num_iterations must be positive");
+    PICP_REQUIRE(hist == nullptr || hist_rows >= sched->num_iterations,
+                 "picp_run_enqueue: history has %d rows, num_iterations is %d", hist_rows, sched->num_iterations);
+    if (int rc = check_pose(w_T_c0_host)) return rc;
+    if (int rc = check_corr(u, v, x, y, z, M)) return rc;
+    const bool on_chip = M > 0 && M <= resident_capacity(ctx);
+    const bool streamed = M > resident_capacity(ctx) && ctx->resident_limit > 0 && M <= ctx->persistent_limit &&
+                          aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
+    PICP_REQUIRE(on_chip || streamed, "picp_run_enqueue: %lld correspondences do not run as a single launch here "
+                 "(empty input, unaligned arrays, or single launches switched off): use picp_run", (long long)M);
+    DeviceGuard g(ctx->device);
+    double* host_state = ctx->pinned + PINNED_SLOT0 + (size_t)slot * PINNED_SLOT_STRIDE;
+    const int rc = on_chip ? enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
+                                              host_state, nullptr, nullptr)
+                           : enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist,
+                                                (int)hist_rows, host_state, nullptr, nullptr);
+    if (rc != PICP_OK) return rc;
+    PICP_HIP_CHECK(hipEventRecord(ctx->slot_done[slot], ctx->stream));
+    resident_refill(ctx);
+    return PICP_OK;
+}
+
+int picp_run_collect(picp_ctx* ctx, int32_t slot, const double* w_T_c0_host, picp_result* result) {
+    PICP_REQUIRE(ctx && result, "picp_run_collect: null argument");
+    PICP_REQUIRE(slot >= 0 && slot < PICP_ASYNC_SLOTS, "picp_run_collect: slot %d is not in 0..%d", (int)slot,
+                 PICP_ASYNC_SLOTS - 1);
+    DeviceGuard g(ctx->device);
+    PICP_HIP_CHECK(hipEventSynchronize(ctx->slot_done[slot]));
+    const double* h = ctx->pinned + PINNED_SLOT0 + (size_t)slot * PINNED_SLOT_STRIDE;
+    if (h[ST_STOP] == 0.0) { // the launch was abandoned at a grid-wide wait
+        ctx->resident_aborts += 1;
+        set_error("picp_run_collect: the launch of slot %d gave up at an exchange (device shared with other work)", (int)slot);
+        return PICP_ERR_RETRY;
+    }
+    result_from_state(h, w_T_c0_host, result);
+    return PICP_OK;
+}
+
 int picp_run_batched(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, const int64_t* offsets, int32_t B, const double* poses0,
                      const picp_camera* cam, const picp_schedule* sched, picp_result* results, double* hist,

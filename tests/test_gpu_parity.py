@@ -506,6 +506,33 @@ def test_loop_plan_equals_run(ctx):
         assert np.array_equal(np.array(list(res_p.T)), np.array(list(res.T)))
 
 
+def test_enqueued_loops_equal_synchronous_ones(ctx):
+    """picp_run_enqueue / picp_run_collect: four loops in flight over the same arrays from different
+    start poses, on-chip and streamed single launches; every result equals picp_run's."""
+    starts = [np.eye(4), po.v2T([0.1, 0.0, -0.1, 0.01, 0.0, 0.02]), po.v2T([-0.05, 0.02, 0.1, 0.0, 0.03, -0.01]), np.eye(4)]
+    cam, sched = bundled_cam(), yaml_sched(25)
+    for M, limit in ((50_001, None), (30_000, 1)):           # limit 1: the streaming single launch
+        uv, pw, _ = make_problem(M, seed=8)
+        corr = ctx.soa(uv, pw)
+        try:
+            ctx.set_resident_limit(limit)
+            expected = [ctx.run(corr, s, cam, sched, want_history=False)[0] for s in starts]
+            expected = [(r.num_iterations, r.best_index, bool(r.valid), np.array(list(r.T))) for r in expected]
+            plan = ctx.plan(corr, cam, sched)
+            for rounds in range(2):                          # slots are reused
+                for k, s in enumerate(starts):
+                    plan.enqueue(s, k)
+                for k in range(len(starts)):
+                    r = plan.collect(k)
+                    n_it, best, valid, T = expected[k]
+                    assert (r.num_iterations, r.best_index, bool(r.valid)) == (n_it, best, valid), (M, k)
+                    assert np.array_equal(np.array(list(r.T)), T), (M, k)
+        finally:
+            ctx.set_resident_limit(None)
+    with pytest.raises(L.PicpError):                          # nothing to enqueue for an empty input
+        ctx.plan(ctx.soa(np.zeros((0, 2)), np.zeros((0, 3))), cam, sched).enqueue(np.eye(4), 0)
+
+
 def test_beyond_the_on_chip_capacity_one_launch_streams(ctx):
     """Just above the on-chip capacity picp_run switches by itself to the single launch that streams
     the arrays: same counts as the oracle, poses within 1e-9, and the same as the stage launches."""
