@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
     __shared__ StepShared sh;
     const int prob = blockIdx.x;
     const int64_t beg = offsets[prob];
-    const int cnt = (int)(offsets[prob + 1] - beg);
+    const int64_t cnt = offsets[prob + 1] - beg;
     if (threadIdx.x == 0) init_state(st, poses0 + (size_t)prob * 16, sc.kernel_threshold, sc.damping, sc.num_iterations);
     __syncthreads();
     double* myhist = (hist != nullptr) ? hist + (size_t)prob * hist_rows * PICP_HIST_STRIDE : nullptr;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
         for (int i = 0; i < 12; ++i) T[i] = st[ST_C_T_W + i];
         const double thr = st[ST_THR];
         Stage1Sums a{0.0, 0u, 0u};
-        for (int i = threadIdx.x; i < cnt; i += NT) {
+        for (int64_t i = threadIdx.x; i < cnt; i += NT) {
             double px = x[beg + i], py = y[beg + i], pz = z[beg + i];
             homogeneous_nan(px, py, pz);
             stage1_point<PINHOLE>(T, cam, thr, u[beg + i], v[beg + i], px, py, pz, a);
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(NT) void icp_batched_kernel(const double* __restric
                 const bool all = (st[ST_MODE] != 0.0);
                 Stage2Sums s;
                 s.clear();
-                for (int i = threadIdx.x; i < cnt; i += NT) {
+                for (int64_t i = threadIdx.x; i < cnt; i += NT) {
                     double px = x[beg + i], py = y[beg + i], pz = z[beg + i];
                     homogeneous_nan(px, py, pz);
                     stage2_point<PINHOLE>(T, cam, thr, mean, all, u[beg + i], v[beg + i], px, py, pz, s);
@@ -327,7 +327,7 @@ int picp_stage1(picp_ctx* ctx, const double* u, const double* v, const double* x
     // the end of its share in that XCD's L2 (per iteration: 2^21 correspondences 40.3 -> 36.6 us,
     // 2^22 62 -> 59, 2^23 111.8 -> 109.4; nothing from 12 M on).
     if (vec && stage2_reverse(ctx, M) && M * 5 * (int64_t)sizeof(double) <= (int64_t(384) << 20)) {
-        const int gridw = grid_for((M + 1) / 2, NT2, ctx->max_blocks2);
+        const int gridw = grid_for((M + 1) / 2, NT2, ctx->max_blocks2 < ctx->max_blocks1 ? ctx->max_blocks2 : ctx->max_blocks1); // part1 holds max_blocks1 records
         ctx->rows1 = gridw;
         auto kw = is_pinhole(cam->K) ? stage1_kernel<2, true, NT2> : stage1_kernel<2, false, NT2>;
         hipLaunchKernelGGL(kw, dim3(gridw), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, ctx->part1);

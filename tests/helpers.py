@@ -34,3 +34,16 @@ def b_err(b, b_ref, H_ref, n_inliers, error):
     scale = np.sqrt(np.max(np.diag(H_ref)) * n_inliers * error)
     scale = max(scale, np.max(np.abs(b_ref)), 1e-300)
     return float(np.max(np.abs(b - b_ref)) / scale)
+
+
+def entry_err(H, H_ref):
+    """Largest error of an entry of H = sum J^T J relative to that entry's own scale sqrt(H_ii H_jj)
+    (|H_ij| <= sqrt(H_ii H_jj) by Cauchy-Schwarz).  H's translation and rotation blocks differ by orders
+    of magnitude, so a norm-relative check would let a small block be wrong at far more than the bar."""
+    H = np.asarray(H, dtype=np.float64).reshape(6, 6)
+    H_ref = np.asarray(H_ref, dtype=np.float64).reshape(6, 6)
+    d = np.sqrt(np.abs(np.diag(H_ref)))
+    scale = np.outer(d, d)
+    if not np.all(scale > 0):
+        return rel_err(H, H_ref) if np.max(np.abs(H_ref)) > 0 else float(np.max(np.abs(H)))
+    return float(np.max(np.abs(H - H_ref) / scale))
