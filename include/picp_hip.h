@@ -246,6 +246,26 @@ int picp_linearize(picp_ctx* ctx, const double* u, const double* v, const double
                    double kernel_threshold, int32_t min_inliers, double* H, double* b, int64_t* num_inliers,
                    double* error, int64_t* n_inside);
 
+/* picp_linearize for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference; it
+ * computes what picp_linearize computes, with the same kernels, but every intermediate (the state
+ * block, the per-workgroup records of both scans, the folded records) lives in a device array that is
+ * part of the library's code object (146 KiB on every GPU the library runs on, held until the process
+ * ends), and the results go to caller-owned DEVICE memory instead of host variables:
+ *   out[0..35] H row-major, out[36..41] b, out[42] num_inliers, out[43] error, out[44] n_inside,
+ *   out[45..47] zero                                         (PICP_LINEARIZE_OUT_DOUBLES doubles).
+ * The call only enqueues kernels on the ctx's stream: no hipMalloc / hipFree, no host-device copy and
+ * no synchronisation (w_T_c0_host and cam are read before it returns).  Inputs of more than
+ * PICP_NOALLOC_MAX_CORRESPONDENCES correspondences are refused with PICP_ERR_CAPACITY.
+ * All calls on one GPU share that GPU's array, whatever their ctx or stream: calls that overlap in
+ * time on one GPU race; order them on one stream or by events.  Nothing in the array needs to be
+ * cleared between calls (every call rewrites what it reads). */
+#define PICP_LINEARIZE_OUT_DOUBLES 48
+#define PICP_NOALLOC_MAX_CORRESPONDENCES (((int64_t)1) << 32)
+int picp_linearize_noalloc(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                           const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
+                           double kernel_threshold, int32_t min_inliers, double* out);
+
 /* ---- appearance association (src/data_association.py:3-57) ---------------------------------
  * All pairs (i, j) whose D-component descriptors are equal component by component under float
  * equality (-0.0 == 0.0, NaN never equal: Python list equality at :31), in i-major, j-minor

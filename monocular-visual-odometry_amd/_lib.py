@@ -27,6 +27,9 @@ H_DX, H_B, H_H = 26, 32, 38
 # state block layout (csrc/picp_device.h)
 ST_W_T_C, ST_C_T_W, ST_THR, ST_LAMBDA, ST_IT, ST_STOP = 0, 16, 32, 33, 39, 40
 
+LINEARIZE_OUT_DOUBLES = 48
+NOALLOC_MAX_CORRESPONDENCES = 1 << 32
+
 PICP_OK = 0
 PICP_ERR_CAPACITY = -3
 PICP_ERR_COMM = -5
@@ -100,6 +103,8 @@ _SIGNATURES = {
     "picp_linearize": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_double,
                                  C.c_int32, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
+    "picp_linearize_noalloc": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_double,
+                                         C.c_int32, _P]),
     "picp_associate": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64,
                                  C.POINTER(C.c_int64)]),
     "picp_set_association_mode": (C.c_int, [_P, C.c_int32]),
@@ -322,6 +327,15 @@ class Context:
                                       float(kernel_threshold), int(min_inliers), H.ctypes.data_as(_P),
                                       b.ctypes.data_as(_P), C.byref(n), C.byref(err), C.byref(nin)), "picp_linearize")
         return H.reshape(6, 6), b, int(n.value), float(err.value), int(nin.value)
+
+    def linearize_noalloc(self, corr, w_T_c0, cam: CameraStruct, kernel_threshold, min_inliers, out):
+        """picp_linearize_noalloc: the same computation with no allocation inside the call; the results go
+        to ``out`` (device tensor of LINEARIZE_OUT_DOUBLES float64: H, b, num_inliers, error, n_inside).
+        Only enqueues; all calls on one GPU share one static workspace and must not overlap."""
+        pose, pose_p = _host16(w_T_c0)
+        check(self.lib.picp_linearize_noalloc(self.handle, *[self.ptr(c) for c in corr], int(corr[0].numel()), pose_p,
+                                              C.byref(cam), float(kernel_threshold), int(min_inliers), self.ptr(out)),
+              "picp_linearize_noalloc")
 
     # ---- association ---------------------------------------------------------------------------
     def set_association_mode(self, mode="auto"):

@@ -33,6 +33,7 @@ struct picp_ctx {
     int assoc_mode;           // 0 auto, 1 all-pairs scan, 2 hash join
     int assoc_hash_fallbacks; // hash joins abandoned for the all-pairs scan (heavy duplication)
     double* pinned; // host-pinned staging for small read-backs
+    double* noalloc; // this device's address of the static workspace of picp_linearize_noalloc
     // register-resident loop (picp_resident.hip)
     double* rslots;                // [3][num_cus][PICP_S2_DOUBLES] exchange records
     int64_t resident_limit;        // largest M the resident loop is used for (0: never)
@@ -62,6 +63,9 @@ enum : int { PINNED_DOUBLES = 4096, PINNED_SLOT0 = 2048, PINNED_SLOT_STRIDE = 12
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+
+// picp_icp.hip
+int noalloc_bind(picp_ctx* ctx);
 
 // picp_resident.hip
 int64_t resident_capacity(const picp_ctx* ctx);

@@ -82,6 +82,10 @@ int picp_create(picp_ctx** out, int device, void* stream) {
         picp_destroy(ctx);
         return hip_fail(e, "picp_create allocations");
     }
+    if (int rc = noalloc_bind(ctx)) { // address of the static workspace on this device
+        picp_destroy(ctx);
+        return rc;
+    }
     *out = ctx;
     return PICP_OK;
 }

@@ -290,6 +290,115 @@ static int check_pose(const double* T) {
     return PICP_OK;
 }
 
+// Launches the stage-1 scan with its per-workgroup records going to `part` (room for `max_rows`
+// records); *rows receives the number of records written.
+static int launch_stage1(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                         const double* z, int64_t M, const double* state, const picp_camera* cam, double* part,
+                         int max_rows, int* rows) {
+    const CameraK c = to_device_camera(cam);
+    const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
+    // above ~4M correspondences one workgroup per CU streams as fast and leaves half the records
+    const int cap1 = (M > (int64_t(1) << 22) && max_rows >= 2 * ctx->num_cus) ? ctx->num_cus : max_rows;
+    const int grid = grid_for(vec ? (M + 1) / 2 : M, NT, cap1);
+    auto kern = vec ? (is_pinhole(cam->K) ? stage1_kernel<2, true> : stage1_kernel<2, false>)
+                    : (is_pinhole(cam->K) ? stage1_kernel<1, true> : stage1_kernel<1, false>);
+    // Where stage 2 runs against stage 1's direction and the arrays are not much larger than the
+    // memory-side cache, stage 1 takes stage 2's workgroup shape and grid: every workgroup then scans
+    // the same share of the arrays in both stages (and sits on the same XCD), so stage 2 also finds
+    // the end of its share in that XCD's L2 (per iteration: 2^21 correspondences 40.3 -> 36.6 us,
+    // 2^22 62 -> 59, 2^23 111.8 -> 109.4; nothing from 12 M on).
+    if (vec && stage2_reverse(ctx, M) && M * 5 * (int64_t)sizeof(double) <= (int64_t(384) << 20)) {
+        const int wide_cap = ctx->max_blocks2 < max_rows ? ctx->max_blocks2 : max_rows; // `part` holds max_rows records
+        const int gridw = grid_for((M + 1) / 2, NT2, wide_cap);
+        *rows = gridw;
+        auto kw = is_pinhole(cam->K) ? stage1_kernel<2, true, NT2> : stage1_kernel<2, false, NT2>;
+        hipLaunchKernelGGL(kw, dim3(gridw), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, part);
+        PICP_HIP_CHECK(hipGetLastError());
+        return PICP_OK;
+    }
+    *rows = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, part);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+// Launches the stage-2 scan: folds the `s1rows` stage-1 records at `s1part`, leaves its own
+// per-workgroup records in `part` (room for `max_rows`); *rows receives their number.
+static int launch_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                         const double* z, int64_t M, const double* state, const picp_camera* cam, const double* s1part,
+                         int s1rows, double* part, int max_rows, int* rows) {
+    const CameraK c = to_device_camera(cam);
+    const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
+    const int grid = grid_for(vec ? (M + 1) / 2 : M, NT2, max_rows);
+    *rows = grid;
+    auto kern = vec ? (is_pinhole(cam->K) ? stage2_kernel<2, true> : stage2_kernel<2, false>)
+                    : (is_pinhole(cam->K) ? stage2_kernel<1, true> : stage2_kernel<1, false>);
+    const bool reverse = stage2_reverse(ctx, M);
+    if (vec && reverse) kern = is_pinhole(cam->K) ? stage2_kernel<2, true, true> : stage2_kernel<2, false, true>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, s1part, s1rows, part);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
+}
+
+// ---- picp_linearize for callers that cannot allocate ------------------------------------------
+// Everything picp_linearize keeps in the ctx's hipMalloc'd workspace (the loop state block, the
+// per-workgroup records of both scans and the two folded records) lives in one file-scope device
+// array instead, so the entry point needs no allocation of any kind.  Every GPU the library runs
+// on holds its own copy of the array until the process ends; its address on a device is looked up
+// once, when a ctx is created on that device (noalloc_bind), and that address -- never the
+// array's name, which in host code is only a handle for the lookup -- is what kernels receive.
+constexpr int NOALLOC_MAX_WG = 512; // per-workgroup records of one scan that fit the array
+enum : int {
+    NA_STATE = 0,                                      // PICP_STATE_DOUBLES
+    NA_S1 = 128,                                       // folded stage-1 record
+    NA_S2 = 160,                                       // folded stage-2 record
+    NA_PART1 = 256,                                    // [NOALLOC_MAX_WG][PICP_S1_DOUBLES]
+    NA_PART2 = NA_PART1 + NOALLOC_MAX_WG * PICP_S1_DOUBLES, // [NOALLOC_MAX_WG][PICP_S2_DOUBLES]
+    NA_DOUBLES = NA_PART2 + NOALLOC_MAX_WG * PICP_S2_DOUBLES, // 18 688 doubles = 146 KiB per GPU
+};
+static __device__ __align__(256) double scratch[NA_DOUBLES];
+
+int noalloc_bind(picp_ctx* ctx) { // called by picp_create with the ctx's device current
+    double* p = nullptr;
+    PICP_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
+    ctx->noalloc = p;
+    return PICP_OK;
+}
+
+// The set choice of __linearize (src/ProjectiveICP.py:300-310, :319-321) on the folded records, on
+// the device: `out` receives H[36], b[6], num_inliers, error, n_inside (PICP_LINEARIZE_OUT_DOUBLES).
+// When the record holds the mean-filtered set and that set is too small (:307), nothing is written:
+// the state's mode flag is set and the caller's second stage-2 launch re-sums the stage-1 set;
+// otherwise the state's stop flag is set, which turns that second round into no-ops.
+__global__ void linearize_decide_kernel(double* __restrict__ state, const double* __restrict__ s1,
+                                        const double* __restrict__ s2, int min_inliers, double* __restrict__ out) {
+    if (state[ST_STOP] != 0.0) return;
+    const int tid = threadIdx.x;
+    const bool none = (s1[S1_COUNT] == 0.0); // :300
+    const bool redo_mode = (state[ST_MODE] != 0.0);
+    if (!none && !redo_mode && s2[S2_N] < (double)min_inliers) {
+        if (tid == 0) state[ST_MODE] = 1.0;
+        return;
+    }
+    if (tid < 36) {
+        const int i = tid / 6, j = tid % 6;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int tri = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+        out[tid] = none ? 0.0 : s2[S2_H + tri];
+    } else if (tid < 42) {
+        out[tid] = none ? 0.0 : s2[S2_B + (tid - 36)];
+    } else if (tid == 42) {
+        out[42] = none ? 0.0 : s2[S2_N];
+    } else if (tid == 43) {
+        out[43] = (!none && s2[S2_N] > 0.0) ? s2[S2_CHI] / s2[S2_N] : d_inf();
+    } else if (tid == 44) {
+        out[44] = s1[S1_N_INSIDE];
+    } else if (tid < PICP_LINEARIZE_OUT_DOUBLES) {
+        out[tid] = 0.0;
+    }
+    if (tid == 63) state[ST_STOP] = 1.0;
+}
+
 } // namespace picp
 
 using namespace picp;
@@ -313,30 +422,7 @@ int picp_stage1(picp_ctx* ctx, const double* u, const double* v, const double* x
     PICP_REQUIRE(ctx && state && cam, "picp_stage1: null argument");
     if (int rc = check_corr(u, v, x, y, z, M)) return rc;
     DeviceGuard g(ctx->device);
-    const CameraK c = to_device_camera(cam);
-    const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
-    // above ~4M correspondences one workgroup per CU streams as fast and leaves half the records
-    const int cap1 = (M > (int64_t(1) << 22) && ctx->max_blocks1 == 2 * ctx->num_cus) ? ctx->num_cus : ctx->max_blocks1;
-    const int grid = grid_for(vec ? (M + 1) / 2 : M, NT, cap1);
-    ctx->rows1 = grid;
-    auto kern = vec ? (is_pinhole(cam->K) ? stage1_kernel<2, true> : stage1_kernel<2, false>)
-                    : (is_pinhole(cam->K) ? stage1_kernel<1, true> : stage1_kernel<1, false>);
-    // Where stage 2 runs against stage 1's direction and the arrays are not much larger than the
-    // memory-side cache, stage 1 takes stage 2's workgroup shape and grid: every workgroup then scans
-    // the same share of the arrays in both stages (and sits on the same XCD), so stage 2 also finds
-    // the end of its share in that XCD's L2 (per iteration: 2^21 correspondences 40.3 -> 36.6 us,
-    // 2^22 62 -> 59, 2^23 111.8 -> 109.4; nothing from 12 M on).
-    if (vec && stage2_reverse(ctx, M) && M * 5 * (int64_t)sizeof(double) <= (int64_t(384) << 20)) {
-        const int gridw = grid_for((M + 1) / 2, NT2, ctx->max_blocks2 < ctx->max_blocks1 ? ctx->max_blocks2 : ctx->max_blocks1); // part1 holds max_blocks1 records
-        ctx->rows1 = gridw;
-        auto kw = is_pinhole(cam->K) ? stage1_kernel<2, true, NT2> : stage1_kernel<2, false, NT2>;
-        hipLaunchKernelGGL(kw, dim3(gridw), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, ctx->part1);
-        PICP_HIP_CHECK(hipGetLastError());
-        return PICP_OK;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, ctx->part1);
-    PICP_HIP_CHECK(hipGetLastError());
-    return PICP_OK;
+    return launch_stage1(ctx, u, v, x, y, z, M, state, cam, ctx->part1, ctx->max_blocks1, &ctx->rows1);
 }
 
 int picp_stage1_reduce(picp_ctx* ctx, double* s1) {
@@ -353,20 +439,8 @@ int picp_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x
     PICP_REQUIRE(ctx && state && cam, "picp_stage2: null argument");
     if (int rc = check_corr(u, v, x, y, z, M)) return rc;
     DeviceGuard g(ctx->device);
-    const CameraK c = to_device_camera(cam);
-    const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
-    const int grid = grid_for(vec ? (M + 1) / 2 : M, NT2, ctx->max_blocks2);
-    ctx->rows2 = grid;
-    const double* s1p = s1 ? s1 : ctx->part1;
-    const int s1rows = s1 ? 1 : ctx->rows1;
-    auto kern = vec ? (is_pinhole(cam->K) ? stage2_kernel<2, true> : stage2_kernel<2, false>)
-                    : (is_pinhole(cam->K) ? stage2_kernel<1, true> : stage2_kernel<1, false>);
-    const bool reverse = stage2_reverse(ctx, M);
-    if (vec && reverse) kern = is_pinhole(cam->K) ? stage2_kernel<2, true, true> : stage2_kernel<2, false, true>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, s1p, s1rows,
-                       ctx->part2);
-    PICP_HIP_CHECK(hipGetLastError());
-    return PICP_OK;
+    return launch_stage2(ctx, u, v, x, y, z, M, state, cam, s1 ? s1 : ctx->part1, s1 ? 1 : ctx->rows1, ctx->part2,
+                         ctx->max_blocks2, &ctx->rows2);
 }
 
 int picp_profile_stage2(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
@@ -670,6 +744,51 @@ int picp_linearize(picp_ctx* ctx, const double* u, const double* v, const double
     for (int i = 0; i < 6; ++i) b[i] = hs2[S2_B + i];
     *num_inliers = (int64_t)hs2[S2_N];
     *error = hs2[S2_N] > 0.0 ? hs2[S2_CHI] / hs2[S2_N] : __builtin_inf();
+    return PICP_OK;
+}
+
+int picp_linearize_noalloc(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                           const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
+                           double kernel_threshold, int32_t min_inliers, double* out) {
+    PICP_REQUIRE(ctx && cam && out, "picp_linearize_noalloc: null argument");
+    if (int rc = check_corr(u, v, x, y, z, M)) return rc;
+    if (M > PICP_NOALLOC_MAX_CORRESPONDENCES) {
+        set_error("picp_linearize_noalloc: %lld correspondences exceed the limit of %lld of the entry point that "
+                  "allocates nothing; use picp_linearize", (long long)M, (long long)PICP_NOALLOC_MAX_CORRESPONDENCES);
+        return PICP_ERR_CAPACITY;
+    }
+    PICP_REQUIRE(ctx->noalloc != nullptr, "picp_linearize_noalloc: the ctx has no address for the static workspace");
+    picp_schedule sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.num_iterations = 1;
+    sc.min_inliers = min_inliers;
+    sc.kernel_threshold = kernel_threshold;
+    sc.damping = 1.0;
+    double* ws = ctx->noalloc; // this device's copy of the static array
+    double* state = ws + NA_STATE;
+    double* s1 = ws + NA_S1;
+    double* s2 = ws + NA_S2;
+    double* part1 = ws + NA_PART1;
+    double* part2 = ws + NA_PART2;
+    if (int rc = picp_state_init(ctx, state, w_T_c0_host, &sc)) return rc; // pose travels as a kernel argument
+    DeviceGuard g(ctx->device);
+    const int cap1 = ctx->max_blocks1 < NOALLOC_MAX_WG ? ctx->max_blocks1 : NOALLOC_MAX_WG;
+    const int cap2 = ctx->max_blocks2 < NOALLOC_MAX_WG ? ctx->max_blocks2 : NOALLOC_MAX_WG;
+    int rows1 = 0, rows2 = 0;
+    if (int rc = launch_stage1(ctx, u, v, x, y, z, M, state, cam, part1, cap1, &rows1)) return rc;
+    hipLaunchKernelGGL(fold_kernel<PICP_S1_DOUBLES>, dim3(1), dim3(NT), 0, ctx->stream, (const double*)part1, rows1,
+                       (const double*)nullptr, s1);
+    // two rounds of {stage 2, fold, decide}: the second one only does something when the first found
+    // the mean-filtered set too small (src/ProjectiveICP.py:307-310); every kernel of it returns at
+    // once when the first round has set the stop flag
+    for (int round = 0; round < 2; ++round) {
+        if (int rc = launch_stage2(ctx, u, v, x, y, z, M, state, cam, s1, 1, part2, cap2, &rows2)) return rc;
+        hipLaunchKernelGGL(fold_kernel<PICP_S2_DOUBLES>, dim3(1), dim3(NT), 0, ctx->stream, (const double*)part2, rows2,
+                           (const double*)state, s2);
+        hipLaunchKernelGGL(linearize_decide_kernel, dim3(1), dim3(64), 0, ctx->stream, state, (const double*)s1,
+                           (const double*)s2, (int)min_inliers, out);
+    }
+    PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
 }
 
