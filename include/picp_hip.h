@@ -234,6 +234,42 @@ int picp_sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const d
                         const picp_schedule* sched, double* s1, double* s2, double* hist, int32_t hist_rows,
                         int32_t rounds);
 
+/* ---- sharded runs with the exchange INSIDE the kernel -----------------------------------------
+ * The single-launch loop on every rank's slice, the two sums of :301 and :313-317 exchanged between the
+ * GPUs by the kernels themselves: after the workgroups of a GPU have combined their sums, one workgroup
+ * stores the GPU's record into a slot of every peer's exchange memory (device memory of the peer, mapped
+ * through HIP IPC; the stores travel over xGMI), and every workgroup adds the `world` records in rank
+ * order.  No launch and no library collective per iteration; all ranks compute bit-identical states.
+ * The reference has no counterpart (it is one process).
+ * Set-up, collective over the ranks (one process per GPU, at most PICP_PEER_MAX_RANKS):
+ *   picp_peer_create   allocates this rank's exchange memory and writes its IPC handle
+ *                      (PICP_PEER_HANDLE_BYTES bytes, host) for the caller to hand to every rank;
+ *   picp_peer_connect  maps the exchange memory of all ranks; handles: host, [world][PICP_PEER_HANDLE_BYTES]
+ *                      in rank order (this rank's own entry is ignored).  All ranks must have returned
+ *                      from picp_peer_create before any rank calls it, and from picp_peer_connect before
+ *                      any rank runs a loop;
+ *   picp_peer_destroy  unmaps and frees (all ranks must have finished their loops).
+ * picp_run_sharded runs the loop on this rank's slice (M may be 0) and synchronises; every rank must
+ * call it with the same pose, camera and schedule.  Results as picp_run, identical on all ranks.
+ * Every wait inside the kernel is bounded: if a peer's record does not arrive (a rank died or was
+ * never launched) the launch gives up, the call returns PICP_ERR_RETRY and the exchange is unusable
+ * until it has been destroyed and set up again; callers then fall back to picp_sharded_rounds.
+ * picp_peer_world: ranks of a usable exchange, 0 if there is none. */
+#define PICP_PEER_MAX_RANKS 8
+#define PICP_PEER_HANDLE_BYTES 64
+int picp_peer_create(picp_ctx* ctx, int32_t rank, int32_t world, void* handle_host);
+int picp_peer_connect(picp_ctx* ctx, const void* handles_host);
+int picp_peer_destroy(picp_ctx* ctx);
+int picp_peer_world(picp_ctx* ctx);
+int picp_run_sharded(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
+                     const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
+                     const picp_schedule* sched, double* state, double* hist, int32_t hist_rows,
+                     picp_result* result);
+/* Caps the number of workgroups of the single-launch loops (0: one per compute unit, the default).
+ * For rehearsing a sharded run with several ranks on ONE GPU: the kernels of all ranks must be
+ * resident together, so each may use only its share of the compute units. */
+int picp_set_grid_limit(picp_ctx* ctx, int32_t max_workgroups);
+
 /* Reads the history back (synchronises) and applies the best-iteration rule (:249-257). */
 int picp_finish(picp_ctx* ctx, const double* state, const double* hist, int32_t hist_rows,
                 const double* w_T_c0_host, picp_result* result);

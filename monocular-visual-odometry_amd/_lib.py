@@ -36,10 +36,17 @@ PICP_ERR_COMM = -5
 PICP_ERR_RETRY = -6
 ASYNC_SLOTS = 4
 COMM_ID_BYTES = 128
+PEER_MAX_RANKS = 8
+PEER_HANDLE_BYTES = 64
 
 
 class PicpError(RuntimeError):
     pass
+
+
+class PicpRetry(PicpError):
+    """A single-launch loop gave up at a bounded wait (PICP_ERR_RETRY): nothing was computed; run the
+    loop again on another path."""
 
 
 class CameraStruct(C.Structure):
@@ -99,6 +106,13 @@ _SIGNATURES = {
     "picp_comm_allreduce": (C.c_int, [_P, _P, C.c_int64]),
     "picp_sharded_rounds": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
                                       C.POINTER(ScheduleStruct), _P, _P, _P, C.c_int32, C.c_int32]),
+    "picp_peer_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "picp_peer_connect": (C.c_int, [_P, _P]),
+    "picp_peer_destroy": (C.c_int, [_P]),
+    "picp_peer_world": (C.c_int, [_P]),
+    "picp_run_sharded": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
+                                   C.POINTER(ScheduleStruct), _P, _P, C.c_int32, C.POINTER(ResultStruct)]),
+    "picp_set_grid_limit": (C.c_int, [_P, C.c_int32]),
     "picp_finish": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.POINTER(ResultStruct)]),
     "picp_linearize": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_double,
                                  C.c_int32, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -283,6 +297,37 @@ class Context:
                                rows if want_history else 0, C.byref(res))
         if rc != PICP_OK:
             check(rc, "picp_run")
+        h = hist[: res.num_iterations].cpu().numpy() if want_history else None
+        return res, h
+
+    def set_grid_limit(self, max_workgroups=0):
+        """Cap on the workgroups of the single-launch loops (0: one per compute unit).  For rehearsals of a
+        sharded run with several ranks on one GPU, whose kernels must all be resident together."""
+        check(self.lib.picp_set_grid_limit(self.handle, int(max_workgroups)), "picp_set_grid_limit")
+
+    def peer_world(self):
+        """Ranks of the ctx's usable in-kernel exchange between GPUs (0: none)."""
+        return int(self.lib.picp_peer_world(self.handle))
+
+    def run_sharded(self, corr, w_T_c0, cam: CameraStruct, sched: ScheduleStruct, want_history=True):
+        """picp_run_sharded on this rank's slice: the single-launch loop with the exchange between the GPUs
+        inside the kernel (sharded.init_peer_exchange first; every rank calls this with the same pose and
+        schedule).  Raises PicpRetry when the launch gave up at an exchange."""
+        state = self._run_state
+        if state is None:
+            state = self._run_state = self.empty(STATE_DOUBLES)
+        rows = max(int(sched.num_iterations), 1)
+        hist = self.zeros((rows, HIST_STRIDE)) if want_history else None
+        res = ResultStruct()
+        pose = np.ascontiguousarray(w_T_c0, dtype=np.float64).reshape(16)
+        rc = self.lib.picp_run_sharded(self.handle, corr[0].data_ptr(), corr[1].data_ptr(), corr[2].data_ptr(),
+                                       corr[3].data_ptr(), corr[4].data_ptr(), corr[0].numel(), pose.ctypes.data,
+                                       C.byref(cam), C.byref(sched), state.data_ptr(),
+                                       hist.data_ptr() if want_history else 0, rows if want_history else 0, C.byref(res))
+        if rc == PICP_ERR_RETRY:
+            raise PicpRetry(self.lib.picp_last_error().decode())
+        if rc != PICP_OK:
+            check(rc, "picp_run_sharded")
         h = hist[: res.num_iterations].cpu().numpy() if want_history else None
         return res, h
 

@@ -44,9 +44,17 @@ struct picp_ctx {
     int64_t persistent_limit;      // largest M the streaming single-launch loop is used for (0: never)
     hipEvent_t loop_done;          // recorded behind a single-launch loop; the host waits for it, not for the stream
     hipEvent_t slot_done[PICP_ASYNC_SLOTS]; // the same for loops enqueued with picp_run_enqueue, one per slot
+    int grid_limit;                // cap on the workgroups of the single-launch loops (0: one per CU)
     // sharded runs (picp_comm.hip)
     void* comm;                    // RCCL communicator of this rank, or null
     int comm_rank, comm_world;
+    // sharded runs with the exchange inside the kernel (picp_peer.hip)
+    double* peer_slots[PICP_PEER_MAX_RANKS]; // exchange memory of every rank, mapped here; [peer_rank] is this GPU's own
+    int peer_rank, peer_world;     // peer_world == 0: not set up
+    int peer_connected;            // the peers' memory is mapped
+    int peer_broken;               // a launch gave up at an exchange: the slots are in an unknown state
+    unsigned peer_epoch;           // exchanges between the GPUs completed by earlier launches
+    unsigned peer_spin_limit;      // polls before a workgroup waiting for a peer gives up
 };
 
 namespace picp {
@@ -78,7 +86,9 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
 int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                        const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
                        const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
-                       hipEvent_t e1);
+                       hipEvent_t e1, bool sharded = false);
+void peer_fill(picp_ctx* ctx, double* slots);
+int peer_slot_doubles();
 
 // Whether the second scan of an iteration walks the arrays against the first one's direction: it
 // then starts with what stage 1 read last and ends with what the next stage 1 reads first, which

@@ -75,6 +75,8 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     ctx->resident_limit = INT64_MAX; // i.e. whatever fits (resident_capacity)
     ctx->resident_spin_limit = 1u << 18;
     ctx->persistent_limit = INT64_MAX;
+    ctx->peer_spin_limit = 1u << 20; // about a second: ranks reach their launches at different times
+    if (const char* ex = getenv("PICP_PEER_SPIN_LIMIT")) { int k = atoi(ex); if (k >= 0) ctx->peer_spin_limit = (unsigned)k; }
     if (const char* ep = getenv("PICP_PERSISTENT_LIMIT")) ctx->persistent_limit = atoll(ep);
     if (const char* er = getenv("PICP_RESIDENT")) { if (atoi(er) == 0) ctx->resident_limit = 0; }
     if (const char* es = getenv("PICP_RESIDENT_SPIN_LIMIT")) { int k = atoi(es); if (k >= 0) ctx->resident_spin_limit = (unsigned)k; }
@@ -95,6 +97,7 @@ int picp_destroy(picp_ctx* ctx) {
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)picp_comm_destroy(ctx);
+    if (ctx->peer_world) (void)picp_peer_destroy(ctx);
     if (ctx->part1) (void)hipFree(ctx->part1);
     if (ctx->part2) (void)hipFree(ctx->part2);
     if (ctx->scratch) (void)hipFree(ctx->scratch);

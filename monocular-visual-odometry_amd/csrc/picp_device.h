@@ -32,6 +32,7 @@ enum : int {
     ST_BEST_IT = 52,     // its index
     ST_MODE = 53,        // 0: stage 2 sums the mean-filtered set; 1: it re-sums the stage-1 set (see S2_*)
     ST_N_STAGE2 = 54,    // mean-filter survivors found before a switch to mode 1 (for the history row)
+    ST_XEPOCH = 55,      // sharded single-launch loop: exchanges between the GPUs completed so far (all launches)
     ST_BEST_T = 64,      // [16] pose of that iteration (:254)
     ST_START_T = 80,     // [16] pose on entry, returned when the result is invalid (:251)
 };

@@ -625,6 +625,38 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
     return picp_finish(ctx, state, hist, hist_rows, w_T_c0_host, result);
 }
 
+int picp_run_sharded(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
+                     int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched,
+                     double* state, double* hist, int32_t hist_rows, picp_result* result) {
+    PICP_REQUIRE(ctx && cam && sched && state && result, "picp_run_sharded: null argument");
+    PICP_REQUIRE(sched->num_iterations > 0, "picp_run_sharded: num_iterations must be positive");
+    PICP_REQUIRE(hist == nullptr || hist_rows >= sched->num_iterations,
+                 "picp_run_sharded: history has %d rows, num_iterations is %d", hist_rows, sched->num_iterations);
+    if (int rc = check_pose(w_T_c0_host)) return rc;
+    if (int rc = check_corr(u, v, x, y, z, M)) return rc;
+    PICP_REQUIRE(ctx->peer_connected, "picp_run_sharded: no exchange between the GPUs (picp_peer_create / picp_peer_connect)");
+    if (ctx->peer_broken) {
+        set_error("picp_run_sharded: an earlier launch gave up at an exchange; destroy the exchange and set it up again");
+        return PICP_ERR_RETRY;
+    }
+    PICP_REQUIRE(M == 0 || (aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z)),
+                 "picp_run_sharded: the slices must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    if (int rc = enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
+                                    ctx->pinned, nullptr, nullptr, true))
+        return rc;
+    if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
+    if (ctx->pinned[ST_STOP] == 0.0) {
+        ctx->peer_broken = 1;
+        ctx->resident_aborts += 1;
+        set_error("picp_run_sharded: the launch gave up waiting for a record (of a workgroup or of another rank)");
+        return PICP_ERR_RETRY;
+    }
+    ctx->peer_epoch = (unsigned)ctx->pinned[ST_XEPOCH];
+    result_from_state(ctx->pinned, w_T_c0_host, result);
+    return PICP_OK;
+}
+
 int picp_run_enqueue(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
                      int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched,
                      double* state, double* hist, int32_t hist_rows, int32_t slot) {

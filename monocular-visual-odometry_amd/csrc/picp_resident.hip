@@ -146,6 +146,80 @@ __device__ __forceinline__ bool grid_total(double mine, double& out, const GridE
     return *lds_flag == 0;
 }
 
+// ---- exchange between the GPUs of a sharded run ---------------------------------------------------
+// Every rank (one process per GPU) runs the single-launch loop on its shard.  After the workgroups of
+// a GPU have exchanged their sums (grid_total), workgroup 0 stores that GPU's total into a slot of
+// EVERY rank's exchange memory -- device memory of the peers, mapped into this process -- and every
+// workgroup of every GPU then collects the `world` records from its own GPU's memory and adds them in
+// rank order.  All ranks add the same records in the same order, so the replicated loop states stay
+// bit-identical, as they do between the workgroups of one GPU.
+//
+// Same rules as inside a GPU: an entry that has not arrived holds the sentinel, stores and loads are
+// write-through / uncached (system scope here), every wait is bounded.  Two slots alternate.  Before
+// workgroup 0 publishes exchange e it resets its own GPU's slot of exchange e-1: it has collected the
+// local exchange that precedes e, so every local workgroup has finished reading e-1, and a peer
+// writes into that slot again (exchange e+1) only after it has seen this rank's record of exchange
+// e, which is stored after the reset has been acknowledged.  The exchange count runs on from launch
+// to launch (epoch0), so nothing has to be cleaned between launches.
+constexpr int XS = 2;                         // alternating slots
+constexpr int XR = PICP_PEER_MAX_RANKS;       // records per slot
+struct PeerExchange {
+    double* slots[XR];   // exchange memory of every rank: [XS][XR][RW]; slots[rank] is this GPU's own
+    int rank, world;     // world == 1: no exchange
+    unsigned epoch0;     // exchanges completed by earlier launches
+    unsigned spin_limit; // re-reads before a waiting thread gives up
+};
+
+template <int NV>
+__device__ __forceinline__ bool cross_total(double mine, double& out, const PeerExchange& px, unsigned& xepoch,
+                                            double* lds_a, double* lds_b, int* lds_flag) {
+    constexpr int CW = NV <= 4 ? 4 : RW; // doubles of a record that travel
+    static_assert(XR * RW <= NTR, "one lane per entry of a slot");
+    const int W = px.world;
+    const unsigned e = xepoch++;
+    const int tid = threadIdx.x;
+    __syncthreads(); // lds_a / lds_b are free: every thread is past the reads of the sums before
+    if (tid < CW) lds_a[tid] = (tid < NV) ? mine : 0.0;
+    double* own = px.slots[px.rank];
+    double* cur = own + (size_t)(e % XS) * XR * RW;
+    if (blockIdx.x == 0) {
+        double* old = own + (size_t)((e + XS - 1u) % XS) * XR * RW;
+        if (tid < W * RW)
+            __hip_atomic_store(old + tid, __longlong_as_double((long long)SENTINEL_BITS), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the resets are in memory ...
+        __syncthreads();                                  // ... those of every wave, before any record leaves
+        if (tid < W * CW) {
+            const int peer = tid / CW, col = tid % CW;
+            __hip_atomic_store(px.slots[peer] + (size_t)(e % XS) * XR * RW + (size_t)px.rank * RW + col, lds_a[col],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    const bool reader = tid < W * CW;
+    const int r = tid / CW, col = tid % CW;
+    double v = 0.0;
+    if (reader) {
+        __builtin_amdgcn_s_sleep(FIRST_LOOK_DELAY);
+        unsigned spins = 0;
+        for (;;) {
+            v = __hip_atomic_load(cur + (size_t)r * RW + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!is_sentinel(v)) break;
+            if (++spins > px.spin_limit) {
+                *lds_flag = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        lds_b[tid] = v;
+    }
+    __syncthreads();
+    double tot = 0.0;
+    if (tid < NV)
+        for (int k = 0; k < W; ++k) tot += lds_b[k * CW + tid]; // rank order on every GPU
+    out = tot;
+    return *lds_flag == 0;
+}
+
 // Stage 1 of one correspondence (as stage1_point) that also leaves what stage 2 needs of it in
 // `keep`: chi (NaN when the pair is outside the image or above the threshold, so that every later
 // comparison with it is false) and 1 / (K p)_z, the one division of the projection.
@@ -326,13 +400,14 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
 // prologues and the separate solve launch: about 10 us per iteration, which matters while a scan
 // takes tens of microseconds.  The first loads of the next scan are issued before the exchange
 // that precedes it, so their latency is hidden behind it.
-template <bool PINHOLE, bool REVERSE>
+template <bool PINHOLE, bool REVERSE, bool SHARDED = false>
 __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                             const double* __restrict__ x, const double* __restrict__ y,
                                                             const double* __restrict__ z, int64_t M,
                                                             double* __restrict__ state, StartPose pose0, CameraK cam,
                                                             picp_schedule sc, GridExchange gx, double* __restrict__ hist,
-                                                            int hist_rows, double* __restrict__ host_state) {
+                                                            int hist_rows, double* __restrict__ host_state,
+                                                            PeerExchange px) {
     __shared__ double st[PICP_STATE_DOUBLES];
     __shared__ double lds[NTR];
     __shared__ double lds_fold[NTR];
@@ -351,6 +426,7 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
     __syncthreads();
 
     unsigned epoch = 0;
+    unsigned xepoch = px.epoch0;
     while (st[ST_STOP] == 0.0) {
         double T[12];
 #pragma unroll
@@ -360,8 +436,8 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
         const int it = (int)st[ST_IT];
 
         Stage1Sums a{0.0, 0u, 0u};
-        fwd.run([&](double mu, double mv, double px, double py, double pz) {
-            stage1_point<PINHOLE>(T, cam, thr, mu, mv, px, py, pz, a);
+        fwd.run([&](double mu, double mv, double qx, double qy, double qz) {
+            stage1_point<PINHOLE>(T, cam, thr, mu, mv, qx, qy, qz, a);
         });
         rev.start(u, v, x, y, z, M); // in flight during the exchange
         {
@@ -369,6 +445,10 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
             const double tot = block_sum<3, NTR, false>(vals, lds);
             double g = tot;
             if (gridDim.x > 1 && !grid_total<3, 2>(tot, g, gx, epoch, lds_fold, &flag)) return;
+            if (SHARDED && px.world > 1) {
+                const double local = g;
+                if (!cross_total<3>(local, g, px, xepoch, lds, lds_fold, &flag)) return;
+            }
             if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < 3) ? g : 0.0;
             __syncthreads();
         }
@@ -377,8 +457,8 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
             const double mean = uniform(s1[S1_SUM_CHI] / n1); // np.mean, src/ProjectiveICP.py:301
             Stage2Sums s;
             s.clear();
-            rev.run([&](double mu, double mv, double px, double py, double pz) {
-                stage2_point<PINHOLE>(T, cam, thr, mean, all, mu, mv, px, py, pz, s);
+            rev.run([&](double mu, double mv, double qx, double qy, double qz) {
+                stage2_point<PINHOLE>(T, cam, thr, mean, all, mu, mv, qx, qy, qz, s);
             });
             fwd.start(u, v, x, y, z, M); // the next iteration's first loads
             double vals[S2_USED];
@@ -386,6 +466,10 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
             const double tot = block_sum<S2_USED, NTR, false>(vals, lds);
             double g = tot;
             if (gridDim.x > 1 && !grid_total<S2_USED, 16>(tot, g, gx, epoch, lds_fold, &flag)) return;
+            if (SHARDED && px.world > 1) {
+                const double local = g;
+                if (!cross_total<S2_USED>(local, g, px, xepoch, lds, lds_fold, &flag)) return;
+            }
             if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = (threadIdx.x < S2_USED) ? g : 0.0;
             __syncthreads();
         } else {
@@ -399,6 +483,8 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
         if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
             hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
     }
+    if (SHARDED && threadIdx.x == 0) st[ST_XEPOCH] = (double)xepoch; // exchanges between the GPUs so far (next launch's epoch0)
+    __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < PICP_STATE_DOUBLES) {
         state[threadIdx.x] = st[threadIdx.x];
         if (host_state != nullptr) host_state[threadIdx.x] = st[threadIdx.x];
@@ -544,7 +630,10 @@ static CameraK camera_of(const picp_camera* cam) {
     return c;
 }
 
-static int resident_grid(const picp_ctx* ctx) { return ctx->num_cus < MAX_GRID ? ctx->num_cus : MAX_GRID; }
+static int resident_grid(const picp_ctx* ctx) {
+    const int g = ctx->num_cus < MAX_GRID ? ctx->num_cus : MAX_GRID;
+    return (ctx->grid_limit > 0 && ctx->grid_limit < g) ? ctx->grid_limit : g;
+}
 
 int64_t resident_capacity(const picp_ctx* ctx) {
     const int64_t cap = (int64_t)resident_grid(ctx) * NTR * R_MAX;
@@ -644,12 +733,14 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
 }
 
 // The streaming single-launch loop (icp_persistent_kernel) for 16-byte aligned arrays of any length.
-// Same completion protocol as enqueue_resident.
+// Same completion protocol as enqueue_resident.  sharded: this rank's slice of a sharded run, with the
+// exchange between the GPUs inside the kernel (the ctx's peer exchange must be connected); M may then
+// be zero (a rank without correspondences still takes part in every exchange).
 int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                        const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
                        const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
-                       hipEvent_t e1) {
-    PICP_REQUIRE(M > 0, "persistent loop: no correspondences");
+                       hipEvent_t e1, bool sharded) {
+    PICP_REQUIRE(M > 0 || sharded, "persistent loop: no correspondences");
     const int64_t steps = ((M >> 1) + NTR - 1) / NTR; // workgroups needed for one grid-stride step
     const int grid = (int)(steps < 1 ? 1 : (steps > resident_grid(ctx) ? resident_grid(ctx) : steps));
     if (host_state != nullptr) host_state[ST_STOP] = 0.0;
@@ -660,17 +751,40 @@ int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const do
     ctx->resident_last_grid = grid;
     const CameraK c = camera_of(cam);
     GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
+    PeerExchange px;
+    memset(&px, 0, sizeof(px));
+    px.world = 1;
+    if (sharded) {
+        PICP_REQUIRE(ctx->peer_connected && !ctx->peer_broken, "sharded loop: the exchange between the GPUs is not usable");
+        for (int k = 0; k < ctx->peer_world; ++k) px.slots[k] = ctx->peer_slots[k];
+        px.rank = ctx->peer_rank;
+        px.world = ctx->peer_world;
+        px.epoch0 = ctx->peer_epoch;
+        px.spin_limit = ctx->peer_spin_limit;
+    }
     const bool pin = is_pinhole(cam->K);
-    auto kern = stage2_reverse(ctx, M) ? (pin ? icp_persistent_kernel<true, true> : icp_persistent_kernel<false, true>)
-                                       : (pin ? icp_persistent_kernel<true, false> : icp_persistent_kernel<false, false>);
+    const bool rev = stage2_reverse(ctx, M);
+    auto kern = rev ? (pin ? icp_persistent_kernel<true, true> : icp_persistent_kernel<false, true>)
+                    : (pin ? icp_persistent_kernel<true, false> : icp_persistent_kernel<false, false>);
+    if (sharded)
+        kern = rev ? (pin ? icp_persistent_kernel<true, true, true> : icp_persistent_kernel<false, true, true>)
+                   : (pin ? icp_persistent_kernel<true, false, true> : icp_persistent_kernel<false, false, true>);
     if (e0 != nullptr)
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, pose, c,
-                              *sched, gx, hist, hist_rows, host_state);
+                              *sched, gx, hist, hist_rows, host_state, px);
     else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, u, v, x, y, z, M, state, pose, c, *sched, gx,
-                           hist, hist_rows, host_state);
+                           hist, hist_rows, host_state, px);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
+}
+
+int peer_slot_doubles() { return XS * XR * RW; }
+
+// Sentinels into a rank's exchange memory for the GPUs (set-up only).
+void peer_fill(picp_ctx* ctx, double* slots) {
+    const int n = XS * XR * RW;
+    hipLaunchKernelGGL(resident_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, slots, n);
 }
 
 template <int R>

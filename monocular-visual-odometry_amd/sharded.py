@@ -142,6 +142,54 @@ def shutdown_native_exchange(ctx):
     check(ctx.lib.picp_comm_destroy(ctx.handle), "picp_comm_destroy")
 
 
+def init_peer_exchange(ctx, group=None):
+    """Sets up the in-kernel exchange between the GPUs of ``group`` (default: the world) on ``ctx``: every
+    rank allocates its exchange memory, the HIP IPC handles travel through the existing process group
+    (whatever its backend), every rank maps its peers' memory.  Collective: every rank must call it.
+    Returns True when every rank is connected; otherwise every rank is left without an exchange (and
+    `run_sharded` / `picp_sharded_rounds` are used).  At most PEER_MAX_RANKS ranks, one node."""
+    import torch.distributed as dist
+    lib = ctx.lib
+    if int(lib.picp_peer_world(ctx.handle)) >= 1:
+        return True
+    multi = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if multi else 0
+    world = dist.get_world_size(group) if multi else 1
+    ok = world <= _lib.PEER_MAX_RANKS
+    buf = C.create_string_buffer(_lib.PEER_HANDLE_BYTES)
+    ok = ok and lib.picp_peer_create(ctx.handle, rank, world, buf) == _lib.PICP_OK
+    handles = [bytes(buf.raw) if ok else None]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, handles[0], group=group)      # also: every rank is past its create
+        handles = gathered
+    ok = all(h is not None for h in handles)
+    if ok and world > 1:
+        ok = lib.picp_peer_connect(ctx.handle, b"".join(handles)) == _lib.PICP_OK
+    ok = _agree(ok, group)                                              # also: every rank is past its connect
+    if not ok:
+        lib.picp_peer_destroy(ctx.handle)
+    return ok
+
+
+def shutdown_peer_exchange(ctx, group=None):
+    """Unmaps and frees the exchange memory (collective: every rank has finished its loops)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)
+    check(ctx.lib.picp_peer_destroy(ctx.handle), "picp_peer_destroy")
+
+
+def _agree(ok, group=None):
+    """Logical AND of ``ok`` over the ranks (all ranks get the same answer)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return bool(ok)
+    flags = [None] * dist.get_world_size(group)
+    dist.all_gather_object(flags, bool(ok), group=group)
+    return all(flags)
+
+
 def _all_reduce_sum(t, group, through_host):
     import torch.distributed as dist
     if through_host and t.is_cuda:

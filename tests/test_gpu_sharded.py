@@ -114,6 +114,123 @@ def test_two_ranks_sharing_the_gpu():
     assert np.array_equal(results[0][1], results[1][1])
 
 
+PEER_CASES = [
+    # (M, iterations, start pose as v2T argument, schedule overrides)
+    (600_001, 25, [0, 0, 0, 0, 0, 0], {}),
+    (600_001, 12, [0.02, -0.01, 0.05, 0.004, -0.003, 0.002], {}),                  # same exchange memory, next launch
+    (5, 8, [0, 0, 0, 0, 0, 0], {"min_inliers": 3}),                                # rank 1 holds one correspondence
+    (1, 5, [0, 0, 0, 0, 0, 0], {"min_inliers": 1}),                                # rank 1 holds none
+    (9_000, 40, [1.0, -0.8, 0.5, 0.2, 0.1, -0.15], {"kernel_threshold": 0.5, "min_inliers": 200}),  # zero-inlier rounds
+    (2_000, 40, [0.01, 0.0, 0.02, 0, 0, 0], {"kernel_threshold": 30.0, "min_inliers": 1500}),  # stage-1 set fallback
+    (70_001, 30, [0, 0, 0, 0, 0, 0], {}),
+]
+
+
+def _peer_params(n_it, over):
+    p = dict(min_inliers=10, kernel_threshold=1000.0, min_kernel_threshold=10.0, max_kernel_threshold=2000.0,
+             damping=64.0, min_damping=1.0, max_damping=64.0)
+    p.update(over)
+    return p
+
+
+def _peer_rank(rank, world, port, out):
+    """One rank of the in-kernel exchange rehearsal: all ranks on the box's one GPU, each kernel capped
+    to its share of the compute units so that the kernels of all ranks are resident together."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = importlib.import_module("monocular-visual-odometry_amd")
+    ctx = p._lib.Context(0)
+    ctx.set_grid_limit(240 // world)
+    ok = p.sharded.init_peer_exchange(ctx)
+    results = []
+    if ok:
+        cam = p._lib.camera_struct([[180, 0, 320], [0, 180, 240], [0, 0, 1]], 640, 480)
+        for k, (M, n_it, v0, over) in enumerate(PEER_CASES):
+            uv, pw, _ = make_problem(M, seed=100 + k)
+            lo, hi = p.sharded.shard_bounds(M, rank, world)
+            q = _peer_params(n_it, over)
+            sched = p._lib.schedule_struct(n_it, q["min_inliers"], q["kernel_threshold"], q["min_kernel_threshold"],
+                                           q["max_kernel_threshold"], q["damping"], q["min_damping"], q["max_damping"])
+            res, hist = ctx.run_sharded(ctx.soa(uv[lo:hi], pw[lo:hi]), po.v2T(v0), cam, sched)
+            results.append((np.array(list(res.T)).reshape(4, 4), int(res.valid), int(res.num_iterations),
+                            int(res.best_index), hist.copy()))
+    dist.barrier()
+    # a rank whose peer never launches gives up after its bounded wait and reports it
+    gave_up = None
+    if ok:
+        os.environ["PICP_PEER_SPIN_LIMIT"] = "3000"
+        impatient = p._lib.Context(0)
+        del os.environ["PICP_PEER_SPIN_LIMIT"]
+        impatient.set_grid_limit(240 // world)
+        assert p.sharded.init_peer_exchange(impatient)
+        if rank == 0:
+            uv, pw, _ = make_problem(4096, seed=1)
+            try:
+                impatient.run_sharded(impatient.soa(uv, pw), np.eye(4), cam, p._lib.schedule_struct(5, 10, 1000, 10, 2000, 64, 1, 64))
+                gave_up = False
+            except p._lib.PicpRetry:
+                gave_up = impatient.peer_world() == 0
+        p.sharded.shutdown_peer_exchange(impatient)
+    out.put((rank, ok, results, gave_up))
+    if ok:
+        p.sharded.shutdown_peer_exchange(ctx)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_exchange_inside_the_single_launch_loop(world):
+    """The sharded single-launch loop with its exchange between the ranks inside the kernel
+    (picp_run_sharded), rehearsed with all ranks on the box's one GPU: each rank's exchange memory is
+    mapped into the others through HIP IPC exactly as between GPUs, and the kernels run at the same
+    time.  Counts, thresholds, damping and iteration counts equal the oracle's, poses within 1e-9, and
+    all ranks end with bit-identical results -- over several launches on the same exchange memory,
+    ragged and empty shards, zero-inlier iterations and the fallback to the stage-1 set."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpctx = mp.get_context("spawn")
+    out = mpctx.Queue()
+    procs = [mpctx.Process(target=_peer_rank, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([out.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in got), "the exchange could not be set up"
+    assert got[0][3] is True                                     # the abandoned launch was reported, exchange unusable
+    seen_zero = seen_redo = 0
+    for k, (M, n_it, v0, over) in enumerate(PEER_CASES):
+        uv, pw, _ = make_problem(M, seed=100 + k)
+        q = _peer_params(n_it, over)
+        params = po.IcpParams(num_iterations=n_it, min_inliers=q["min_inliers"], kernel_threshold=q["kernel_threshold"])
+        T_ref, valid_ref, h = po.projective_icp(uv, pw, po.v2T(v0), params, record_linear=True)
+        T0, valid0, n0, best0, hist0 = got[0][2][k]
+        for rank in range(1, world):
+            T, valid, n, best, hist = got[rank][2][k]
+            assert np.array_equal(T, T0) and (valid, n, best) == (valid0, n0, best0) and np.array_equal(hist, hist0), (k, rank)
+        assert n0 == len(h["error"]) and bool(valid0) == valid_ref, k
+        assert np.array_equal(hist0[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h["num_inliers"])), k
+        assert np.array_equal(hist0[:, L.H_N_INSIDE].astype(np.int64), np.array(h["n_inside"])), k
+        assert np.array_equal(hist0[:, L.H_KERNEL_THR], np.array(h["kernel_threshold"], dtype=np.float64)), k
+        assert np.array_equal(hist0[:, L.H_DAMPING], np.array(h["dumping_factor"], dtype=np.float64)), k
+        assert rel_err(hist0[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(h["T"])) < 1e-9, k
+        for i in range(n0):
+            if np.max(np.abs(h["H"][i])) > 0:
+                assert entry_err(hist0[i, L.H_H:L.H_H + 36], h["H"][i]) < 1e-9, (k, i)
+        if valid_ref:
+            kb = best0
+            assert abs(h["error"][kb] - min(h["error"])) <= 1e-9 * abs(min(h["error"])), k
+            assert rel_err(T0, np.array(h["T"])[kb]) < 1e-9, k
+        else:
+            assert rel_err(T0, T_ref) < 1e-9, k
+        seen_zero += int(np.any(hist0[:, L.H_NUM_INLIERS] == 0))
+        seen_redo += int(np.any((hist0[:, L.H_USED_STAGE2] == 0) & (hist0[:, L.H_N_STAGE1] > 0)))
+    assert seen_zero > 0 and seen_redo > 0
+
+
 def _device_problem(ctx, M, seed=0, chunk=1 << 23):
     """The synthetic problem of tests/synthetic.make_problem generated on the device (torch), in
     chunks, as five SoA planes; returns (planes [5][M], true pose)."""
