@@ -265,6 +265,10 @@ int picp_run_sharded(picp_ctx* ctx, const double* u, const double* v, const doub
                      const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
                      const picp_schedule* sched, double* state, double* hist, int32_t hist_rows,
                      picp_result* result);
+/* Timing aid for benchmarks: with timing on, picp_run_sharded brackets its launch with HIP events bound
+ * to that dispatch, and picp_last_launch_ms reports the duration of the last such launch. */
+int picp_set_launch_timing(picp_ctx* ctx, int32_t on);
+int picp_last_launch_ms(picp_ctx* ctx, double* ms);
 /* Caps the number of workgroups of the single-launch loops (0: one per compute unit, the default).
  * For rehearsing a sharded run with several ranks on ONE GPU: the kernels of all ranks must be
  * resident together, so each may use only its share of the compute units. */

@@ -113,6 +113,8 @@ _SIGNATURES = {
     "picp_run_sharded": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
                                    C.POINTER(ScheduleStruct), _P, _P, C.c_int32, C.POINTER(ResultStruct)]),
     "picp_set_grid_limit": (C.c_int, [_P, C.c_int32]),
+    "picp_set_launch_timing": (C.c_int, [_P, C.c_int32]),
+    "picp_last_launch_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "picp_finish": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.POINTER(ResultStruct)]),
     "picp_linearize": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct), C.c_double,
                                  C.c_int32, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_double),

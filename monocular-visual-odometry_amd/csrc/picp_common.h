@@ -55,6 +55,9 @@ struct picp_ctx {
     int peer_broken;               // a launch gave up at an exchange: the slots are in an unknown state
     unsigned peer_epoch;           // exchanges between the GPUs completed by earlier launches
     unsigned peer_spin_limit;      // polls before a workgroup waiting for a peer gives up
+    int time_launches;             // picp_run_sharded brackets its launch with events (picp_set_launch_timing)
+    hipEvent_t prof0, prof1;
+    double last_launch_ms;
 };
 
 namespace picp {

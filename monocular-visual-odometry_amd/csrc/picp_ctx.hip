@@ -104,6 +104,8 @@ int picp_destroy(picp_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->rslots) (void)hipFree(ctx->rslots);
     if (ctx->loop_done) (void)hipEventDestroy(ctx->loop_done);
+    if (ctx->prof0) (void)hipEventDestroy(ctx->prof0);
+    if (ctx->prof1) (void)hipEventDestroy(ctx->prof1);
     for (int k = 0; k < PICP_ASYNC_SLOTS; ++k)
         if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
     if (ctx->assoc_count) (void)hipFree(ctx->assoc_count);

@@ -642,10 +642,21 @@ int picp_run_sharded(picp_ctx* ctx, const double* u, const double* v, const doub
     PICP_REQUIRE(M == 0 || (aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z)),
                  "picp_run_sharded: the slices must be 16-byte aligned");
     DeviceGuard g(ctx->device);
+    if (ctx->time_launches && ctx->prof0 == nullptr) {
+        PICP_HIP_CHECK(hipEventCreate(&ctx->prof0));
+        PICP_HIP_CHECK(hipEventCreate(&ctx->prof1));
+    }
+    hipEvent_t e0 = ctx->time_launches ? ctx->prof0 : nullptr, e1 = ctx->time_launches ? ctx->prof1 : nullptr;
     if (int rc = enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
-                                    ctx->pinned, nullptr, nullptr, true))
+                                    ctx->pinned, e0, e1, true))
         return rc;
     if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
+    if (e0 != nullptr) {
+        float ms = 0.f;
+        PICP_HIP_CHECK(hipEventSynchronize(e1));
+        PICP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        ctx->last_launch_ms = ms;
+    }
     if (ctx->pinned[ST_STOP] == 0.0) {
         ctx->peer_broken = 1;
         ctx->resident_aborts += 1;
@@ -654,6 +665,18 @@ int picp_run_sharded(picp_ctx* ctx, const double* u, const double* v, const doub
     }
     ctx->peer_epoch = (unsigned)ctx->pinned[ST_XEPOCH];
     result_from_state(ctx->pinned, w_T_c0_host, result);
+    return PICP_OK;
+}
+
+int picp_set_launch_timing(picp_ctx* ctx, int32_t on) {
+    PICP_REQUIRE(ctx != nullptr, "picp_set_launch_timing: null ctx");
+    ctx->time_launches = on ? 1 : 0;
+    return PICP_OK;
+}
+
+int picp_last_launch_ms(picp_ctx* ctx, double* ms) {
+    PICP_REQUIRE(ctx != nullptr && ms != nullptr, "picp_last_launch_ms: null argument");
+    *ms = ctx->last_launch_ms;
     return PICP_OK;
 }
 

@@ -94,6 +94,14 @@ class HipStages:
     def stopped(self):
         return bool(self.state[_lib.ST_STOP].item() != 0.0)
 
+    def state_checksum(self):
+        """62-bit checksum of the replicated state block's bit patterns (a one-ulp difference in any of
+        its 96 doubles changes it), for `check_replicas`."""
+        import torch
+        bits = self.state.view(torch.int64)
+        weights = torch.arange(1, 2 * bits.numel(), 2, dtype=torch.int64, device=bits.device)
+        return int((bits * weights).sum().item()) & ((1 << 62) - 1)
+
     def finish(self):
         res = _lib.ResultStruct()
         check(self.ctx.lib.picp_finish(self.ctx.handle, self.ctx.ptr(self.state), self.ctx.ptr(self.hist), self.rows,
@@ -190,6 +198,31 @@ def _agree(ok, group=None):
     return all(flags)
 
 
+def check_replicas(stages, group=None):
+    """Raises PicpError on EVERY rank when the replicated loop states of the ranks differ.
+
+    The sharded loop relies on all ranks holding bit-identical state (same sums from the all-reduce, same
+    deterministic solve): they then leave the loop after the same round.  If that ever fails -- a
+    collective whose result differs between ranks, a rank fed different inputs -- ranks would enqueue
+    different numbers of rounds and the job would hang in a later collective.  Called wherever the stop
+    flag is read back: one all-reduce (MAX) of [c, -c] for a checksum c of the state, i.e. its maximum
+    and minimum over the ranks; every rank sees both and so takes the same decision."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    if not hasattr(stages, "state_checksum"):
+        return
+    c = int(stages.state_checksum())
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.tensor([c, -c], dtype=torch.int64, device=stages.state.device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0].item()), -int(t[1].item())
+    if hi != lo:
+        raise _lib.PicpError("sharded loop: the replicated loop state differs between ranks (state checksums "
+                             f"{lo:#x} .. {hi:#x}, this rank {c:#x}); stopping instead of risking a hang in a collective")
+
+
 def _all_reduce_sum(t, group, through_host):
     import torch.distributed as dist
     if through_host and t.is_cuda:
@@ -231,7 +264,7 @@ def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=
     if native:
         if exchange and not covered:
             raise _lib.PicpError("run_sharded(native=True) needs init_native_exchange over the same ranks first")
-        return _run_native(stages, int(num_iterations), check_every, disable_stop)
+        return _run_native(stages, int(num_iterations), check_every, disable_stop, group)
     if through_host is None:
         through_host = exchange and dist.get_backend(group) != "nccl"
     stages.state_init()
@@ -248,13 +281,16 @@ def run_sharded(stages, num_iterations, group=None, check_every=8, disable_stop=
         stages.solve(s1, s2)
         rounds += 1
         if rounds >= next_check:
-            if stages.stopped():
+            stopped = stages.stopped()
+            if exchange:
+                check_replicas(stages, group)
+            if stopped:
                 break
             next_check = rounds + (1 if disable_stop else check_every)
     return stages.finish()
 
 
-def _run_native(stages, total, check_every, disable_stop):
+def _run_native(stages, total, check_every, disable_stop, group=None):
     """The loop with whole rounds enqueued by the library (its own all-reduces in between, if the ctx
     has a communicator).  Same stop protocol as the generic loop: the flag is read back after every
     chunk of rounds, all ranks read the same value and so enqueue the same number of rounds."""
@@ -264,7 +300,9 @@ def _run_native(stages, total, check_every, disable_stop):
         n = (total if rounds == 0 else 1) if disable_stop else min(check_every, 2 * total - rounds)
         stages.rounds(n)
         rounds += n
-        if stages.stopped():
+        stopped = stages.stopped()
+        check_replicas(stages, group)
+        if stopped:
             break
     return stages.finish()
 

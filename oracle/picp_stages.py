@@ -121,6 +121,33 @@ class NumpyStages:
     def stopped(self):
         return self.stop
 
+    @property
+    def state(self):                                       # where check_replicas puts its tensor
+        return torch.zeros(1)
+
+    def state_checksum(self):
+        """Checksum of the replicated state's bit patterns (sharded.check_replicas)."""
+        vals = np.concatenate([np.asarray(self.w_T_c, dtype=np.float64).reshape(-1), self.ring,
+                               [self.thr, self.lam, self.error_prev, self.mean_slope, self.sigma_slope, self.stuck,
+                                self.flicker, self.it, self.mode, float(self.stop)]]).astype(np.float64)
+        bits = vals.view(np.int64).astype(object)
+        return int(sum(int(b) * (2 * i + 1) for i, b in enumerate(bits))) & ((1 << 62) - 1)
+
+    # Whole rounds with the exchange inside, as the library's picp_sharded_rounds does with its own
+    # communicator: lets the driver's "native" control flow (sharded._run_native) run on CPU ranks.
+    comm_world = 0                                         # set by the test to the number of ranks
+
+    def rounds(self, n):
+        import torch.distributed as dist
+        for _ in range(int(n)):
+            s1 = self.stage1()
+            if self.comm_world > 1:
+                dist.all_reduce(s1, op=dist.ReduceOp.SUM)
+            s2 = self.stage2(s1)
+            if self.comm_world > 1:
+                dist.all_reduce(s2, op=dist.ReduceOp.SUM)
+            self.solve(s1, s2)
+
     def finish(self):
         best = int(np.argmin(self.hist["error"]))
         self.hist["best_index"] = best
