@@ -477,7 +477,18 @@ __device__ __forceinline__ double fold_partials(const double* __restrict__ part,
     return f.finish(part, rows, stride, lds);
 }
 
-// ---- small dense routines used by the solve (one lane) ---------------------------------------
+// ---- small dense routines used by the solve ---------------------------------------
+
+// 1 / p to within an ulp or two: the hardware's reciprocal estimate and two Newton steps, i.e. the
+// front half of an IEEE division without its final rounding correction (half the dependent
+// instructions).  For pivots and determinants inside the solve, which sit on the loop's critical
+// path and whose last bit does not matter; p must be a normal number well inside the exponent range.
+__device__ __forceinline__ double recip_nr(double p) {
+    double r = __builtin_amdgcn_rcp(p);
+    r = __builtin_fma(r, __builtin_fma(-p, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-p, r, 1.0), r);
+    return r;
+}
 
 // Inverse of a pose matrix [A t; 0 0 0 1] as [A^-1, -A^-1 t; 0 0 0 1] with A^-1 = adj(A) / det(A).
 // The reference calls np.linalg.inv (src/ProjectiveICP.py:232), a general LU inverse; a
@@ -493,7 +504,7 @@ __device__ inline void invert_pose(const double* T, double* Tinv) {
     const double c10 = f * g - d * i, c11 = a * i - c * g, c12 = c * d - a * f;
     const double c20 = d * h - e * g, c21 = b * g - a * h, c22 = a * e - b * d;
     const double det = a * c00 + b * c10 + c * c20;
-    const double r = 1.0 / det;
+    const double r = recip_nr(det);
     const double m00 = c00 * r, m01 = c01 * r, m02 = c02 * r;
     const double m10 = c10 * r, m11 = c11 * r, m12 = c12 * r;
     const double m20 = c20 * r, m21 = c21 * r, m22 = c22 * r;
@@ -514,45 +525,6 @@ __device__ inline void invert_pose(const double* T, double* Tinv) {
     Tinv[13] = 0.0;
     Tinv[14] = 0.0;
     Tinv[15] = 1.0;
-}
-
-// Solves (H + lambda I) dx = -b for symmetric positive definite H + lambda I by Cholesky.
-// The reference calls np.linalg.lstsq (src/ProjectiveICP.py:269-270); the damped matrix is SPD
-// (lambda >= min damping > 0), so the least-squares solution is the unique solution.
-__device__ inline void damped_solve6(const double* H /*36, symmetric*/, const double* b, double lambda, double* dx) {
-    // Column-oriented Cholesky; Linv[j] = 1 / L[j][j] replaces the divisions by the diagonal (this
-    // runs on a single lane, where each float64 division is a long dependent instruction chain).
-    double L[6][6], Linv[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        double d = H[j * 6 + j] + lambda;
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-        Linv[j] = rsqrt(d);
-        L[j][j] = d * Linv[j];
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
-            double s = H[i * 6 + j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-            L[i][j] = s * Linv[j];
-        }
-    }
-    double yv[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double s = -b[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) s -= L[i][k] * yv[k];
-        yv[i] = s * Linv[i];
-    }
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-        double s = yv[i];
-#pragma unroll
-        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * dx[k];
-        dx[i] = s * Linv[i];
-    }
 }
 
 // float32 sine and cosine exactly as numpy computes them on x86 with FMA (its AVX2 / AVX-512
@@ -599,16 +571,12 @@ __device__ inline void numpy_sincosf(float x, float* sin_out, float* cos_out) {
 // v2T (src/geometry_utils.py:38-45): translation copied; R = Rx Ry Rz (:19-23) where the angles
 // are first cast to float32 (:41) so each sine/cosine is a float32 value, widened to float64
 // before the two 3x3 products.
-__device__ inline void v2T_device(const double* v, double* T) {
-    float fsx, fcx, fsy, fcy, fsz, fcz;
-    numpy_sincosf((float)v[3], &fsx, &fcx);
-    numpy_sincosf((float)v[4], &fsy, &fcy);
-    numpy_sincosf((float)v[5], &fsz, &fcz);
-    const double cx = fcx, sx = fsx, cy = fcy, sy = fsy, cz = fcz, sz = fsz;
-    // R = (Rx Ry) Rz written out.  The factors hold exact zeros and ones, so in the reference's
-    // two 3x3 products every entry of Rx Ry is a single product and every entry of R a sum of at
-    // most two products; the terms multiplied by zero or one are left out (they do not change a
-    // floating-point sum).
+// R = (Rx Ry) Rz written out from the six sines and cosines (entries 0..2, 4..6, 8..10 of T).  The
+// factors hold exact zeros and ones, so in the reference's two 3x3 products every entry of Rx Ry is a
+// single product and every entry of R a sum of at most two products; the terms multiplied by zero or
+// one are left out (they do not change a floating-point sum).
+__device__ __forceinline__ void rotation_from_sincos(double sx, double cx, double sy, double cy, double sz, double cz,
+                                                     double* T) {
     const double a00 = cy, a02 = sy;                       // Rx Ry, row 0 (a01 = 0)
     const double a10 = sx * sy, a11 = cx, a12 = -(sx * cy); // row 1
     const double a20 = -(cx * sy), a21 = sx, a22 = cx * cy; // row 2
@@ -621,6 +589,14 @@ __device__ inline void v2T_device(const double* v, double* T) {
     T[8] = a20 * cz + a21 * sz;
     T[9] = a21 * cz - a20 * sz;
     T[10] = a22;
+}
+
+__device__ inline void v2T_device(const double* v, double* T) {
+    float fsx, fcx, fsy, fcy, fsz, fcz;
+    numpy_sincosf((float)v[3], &fsx, &fcx);
+    numpy_sincosf((float)v[4], &fsy, &fcy);
+    numpy_sincosf((float)v[5], &fsz, &fcz);
+    rotation_from_sincos(fsx, fcx, fsy, fcy, fsz, fcz, T);
     T[3] = v[0];
     T[7] = v[1];
     T[11] = v[2];
@@ -661,9 +637,10 @@ __device__ inline double numpy_sum10(const double* a) {
 // (src/ProjectiveICP.py:300-321, :269-271, :200-238).  The work has two independent serial chains --
 // the pose chain (damped solve -> v2T -> pose product -> inverse) and the schedule chain (threshold,
 // error-slope statistics, counters, damping, stop test), which needs only the error and the inlier
-// count, i.e. the stage records -- plus copies.  A workgroup runs the two chains on lane 0 of two
-// different waves at the same time, a third wave fills the history row's H and b, and after one
-// barrier the lanes write the state block and the history row in parallel.
+// count, i.e. the stage records -- plus copies.  A workgroup runs the two chains on two different
+// waves at the same time (the pose chain spread over the lanes of its wave, the schedule chain on one
+// lane), a third wave fills the history row's H and b, and after one barrier the lanes write the
+// state block and the history row in parallel.
 
 // Fills the H, b and padding entries of a history row from the stage records (lanes tid = 0..63).
 __device__ __forceinline__ void fill_history_linear(double* hist_row, const double* s1, const double* s2, int tid) {
@@ -691,59 +668,123 @@ struct StepShared {
     int it;        // 1-based number of this iteration (:179)
     int ring_slot; // slot of the slope ring buffer that receives `slope`, or -1
     int improved;  // this iteration's error is the smallest so far (first minimum wins, :249)
+#ifdef PICP_STAMPS
+    unsigned long long t[6]; // diagnostic build: clock stamps inside solve_step
+#endif
 };
 
-// Pose chain, one lane: H and b of the chosen set, damped solve, v2T, pose product, inverse.
-__device__ inline void step_pose_chain(const double* st, const double* s1, const double* s2, StepShared* sh) {
-    double T1[16];
-    double dx[6];
+// Cross-lane reads of a double inside a wave: from a lane every lane names for itself (ds_bpermute:
+// register to register through the LDS crossbar, no memory), or from one fixed lane (v_readlane).
+__device__ __forceinline__ double lane_gather(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int LANE>
+__device__ __forceinline__ double lane_bcast(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
+    return __hiloint2double(hi, lo);
+}
+template <int LANE>
+__device__ __forceinline__ float lane_bcastf(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), LANE));
+}
+
+// Pose chain, one whole wave (all 64 lanes active): H and b of the chosen set, damped solve, v2T, pose
+// product, inverse (src/ProjectiveICP.py:269-271, :232).  On a single lane this is a chain of some
+// three hundred dependent float64 operations, six of them divisions or square roots, and every
+// iteration of the loop waits for it; spread over the lanes it is six elimination steps:
+//   lane 8 i + k holds entry (i, k) of the augmented matrix [H + lambda I | -b] (6 x 7); Gauss-Jordan
+//   step j divides row j by the pivot and subtracts its multiples from every other row, every entry
+//   in its own lane, with the pivot broadcast by v_readlane and the entries (i, j) and (j, k) fetched
+//   by ds_bpermute.  The matrix is symmetric positive definite (lambda >= min damping > 0), for which
+//   elimination without pivoting is stable; the reference's np.linalg.lstsq returns the same unique
+//   solution.  After step 5 column 6 holds dx.
+// The three float32 sine/cosine pairs of v2T are computed by three lanes at once; the rest (pose
+// product, cofactor inverse) has uniform operands and is computed by every lane alike, lane 0 stores it.
+__device__ __forceinline__ void step_pose_wave(const double* st, const double* s1, const double* s2, StepShared* sh) {
+    const int lane = threadIdx.x & 63;
+    double T1[16], dx[6];
+    if (s1[S1_N_INSIDE] == 0.0) { // uniform: __one_step returns before the solve when there are no points (:263)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dx[i] = 0.0;
-    if (s1[S1_N_INSIDE] == 0.0) {
-        // __one_step returns before the solve when there are no points (:263)
+        for (int i = 0; i < 6; ++i) dx[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) T1[i] = st[ST_W_T_C + i];
     } else {
-        double H[36], b[6];
-        if (s1[S1_COUNT] == 0.0) { // :300: H = 0, b = 0
-#pragma unroll
-            for (int i = 0; i < 36; ++i) H[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) b[i] = 0.0;
-        } else {
-            int k = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-#pragma unroll
-                for (int j = i; j < 6; ++j) {
-                    const double h = s2[S2_H + k];
-                    H[i * 6 + j] = h;
-                    H[j * 6 + i] = h;
-                    ++k;
-                }
+        const bool have = (s1[S1_COUNT] != 0.0); // else H = 0, b = 0 (:300)
+        const int i = lane >> 3, k = lane & 7;
+        double a = 0.0;
+        if (i < 6 && k < 7) {
+            if (k < 6) {
+                const int lo = i < k ? i : k, hi = i < k ? k : i;
+                const int tri = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo); // index of (lo, hi) in the row-major upper triangle
+                a = have ? s2[S2_H + tri] : 0.0;
+                if (i == k) a += st[ST_LAMBDA]; // :269
+            } else {
+                a = have ? -s2[S2_B + i] : -0.0; // :270
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) b[i] = s2[S2_B + i];
         }
-        damped_solve6(H, b, st[ST_LAMBDA], dx); // :269-270
+#define PICP_GJ_STEP(J)                                                      \
+    {                                                                        \
+        const double r = recip_nr(lane_bcast<(J) * 8 + (J)>(a));             \
+        const double aij = lane_gather(a, i * 8 + (J));                      \
+        const double ajk = lane_gather(a, (J) * 8 + k);                      \
+        a = (i == (J)) ? a * r : __builtin_fma(-(aij * r), ajk, a);          \
+    }
+        PICP_GJ_STEP(0)
+        PICP_GJ_STEP(1)
+        PICP_GJ_STEP(2)
+        PICP_GJ_STEP(3)
+        PICP_GJ_STEP(4)
+        PICP_GJ_STEP(5)
+#undef PICP_GJ_STEP
+#ifdef PICP_STAMPS
+        if (lane == 0) sh->t[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+        dx[0] = lane_bcast<0 * 8 + 6>(a);
+        dx[1] = lane_bcast<1 * 8 + 6>(a);
+        dx[2] = lane_bcast<2 * 8 + 6>(a);
+        dx[3] = lane_bcast<3 * 8 + 6>(a);
+        dx[4] = lane_bcast<4 * 8 + 6>(a);
+        dx[5] = lane_bcast<5 * 8 + 6>(a);
+        // v2T (src/geometry_utils.py:38-45): lanes 0, 1, 2 take the three angles
+        const double ang = (lane == 0) ? dx[3] : ((lane == 1) ? dx[4] : dx[5]);
+        float fs, fc;
+        numpy_sincosf((float)ang, &fs, &fc);
+        const double sx = lane_bcastf<0>(fs), cx = lane_bcastf<0>(fc);
+        const double sy = lane_bcastf<1>(fs), cy = lane_bcastf<1>(fc);
+        const double sz = lane_bcastf<2>(fs), cz = lane_bcastf<2>(fc);
         double dT[16];
-        v2T_device(dx, dT);
+        rotation_from_sincos(sx, cx, sy, cy, sz, cz, dT);
+        dT[3] = dx[0];
+        dT[7] = dx[1];
+        dT[11] = dx[2];
+        dT[12] = 0.0;
+        dT[13] = 0.0;
+        dT[14] = 0.0;
+        dT[15] = 1.0;
         matmul4(st + ST_W_T_C, dT, T1); // :271
     }
+#ifdef PICP_STAMPS
+    if (lane == 0) sh->t[5] = __builtin_amdgcn_s_memrealtime();
+#endif
     double Tinv[16];
     invert_pose(T1, Tinv);
+    if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        sh->T1[i] = T1[i];
-        sh->Tinv[i] = Tinv[i];
+        for (int i = 0; i < 16; ++i) {
+            sh->T1[i] = T1[i];
+            sh->Tinv[i] = Tinv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sh->dx[i] = dx[i];
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sh->dx[i] = dx[i];
 }
 
 // Schedule chain, one lane: error and inlier count of the chosen set, then :200-228.
 __device__ inline void step_schedule_chain(const double* st, const double* s1, const double* s2,
-                                           const picp_schedule& sc, StepShared* sh) {
+                                           const picp_schedule& sc, StepShared* sh, StepShared& out) {
     const double n_inside = s1[S1_N_INSIDE];
     const double n1 = s1[S1_COUNT];
     const bool redo_mode = (st[ST_MODE] != 0.0);
@@ -800,25 +841,29 @@ __device__ inline void step_schedule_chain(const double* st, const double* s1, c
     if ((lam * 2.0) <= sc.max_damping && flicker > 10.0) lam *= 2.0;
     bool stop = done && (error < 0.01 || stuck > 100.0) && (sc.disable_stop == 0); // :228
     if (it >= sc.num_iterations) stop = true;                                      // :178
-    sh->error = error;
-    sh->n_inliers = n_inliers;
-    sh->n_stage2 = n_stage2;
-    sh->used_stage2 = used_stage2;
-    sh->mean_stage1 = mean_stage1;
-    sh->done = done ? 1.0 : 0.0;
-    sh->thr = thr;
-    sh->lam = lam;
-    sh->mean_slope = mean_slope;
-    sh->sigma_slope = sigma_slope;
-    sh->stuck = stuck;
-    sh->flicker = flicker;
-    sh->slope = slope;
-    sh->stop = stop ? 1.0 : 0.0;
-    sh->it = it;
-    sh->ring_slot = ring_slot;
+    // The results stay in this lane's registers (`out`): the same lane writes them to the state block and
+    // the history row after the workgroup's barrier.  Only `improved` is needed by other lanes.
+    out.error = error;
+    out.n_inliers = n_inliers;
+    out.n_stage2 = n_stage2;
+    out.used_stage2 = used_stage2;
+    out.mean_stage1 = mean_stage1;
+    out.done = done ? 1.0 : 0.0;
+    out.thr = thr;
+    out.lam = lam;
+    out.mean_slope = mean_slope;
+    out.sigma_slope = sigma_slope;
+    out.stuck = stuck;
+    out.flicker = flicker;
+    out.slope = slope;
+    out.stop = stop ? 1.0 : 0.0;
+    out.it = it;
+    out.ring_slot = ring_slot;
     // np.argmin returns the first minimum; NaN would win in numpy, which cannot arise here
     // because a NaN chi never passes chi <= threshold.
-    sh->improved = (it == 1 || error < st[ST_BEST_ERR]) ? 1 : 0;
+    out.improved = (it == 1 || error < st[ST_BEST_ERR]) ? 1 : 0;
+    sh->improved = out.improved;
+    sh->it = it;
 }
 
 // The whole tail, called by every thread of a workgroup of at least 192 threads.
@@ -842,48 +887,71 @@ __device__ __forceinline__ bool solve_step(double* st, const double* s1, const d
         __syncthreads();
         return false;
     }
-    if (tid == 0) step_pose_chain(st, s1, s2, sh);
-    if (tid == 64) step_schedule_chain(st, s1, s2, sc, sh);
+#ifdef PICP_STAMPS
+    if (tid == 0) sh->t[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (tid < 64) step_pose_wave(st, s1, s2, sh);
+#ifdef PICP_STAMPS
+    if (tid == 0) sh->t[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    StepShared mine; // the schedule chain's results, in the registers of the lane that computed them
+    if (tid == 64) step_schedule_chain(st, s1, s2, sc, sh, mine);
+#ifdef PICP_STAMPS
+    if (tid == 64) sh->t[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (hist_row != nullptr && tid >= 128 && tid < 192) fill_history_linear(hist_row, s1, s2, tid - 128);
     __syncthreads();
+#ifdef PICP_STAMPS
+    if (tid == 0) sh->t[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     // state update (:231-238) and history row, one entry per lane
     if (tid < 16) {
         const double t = sh->T1[tid];
+        const double ti = sh->Tinv[tid];
+        const int improved = sh->improved;
         st[ST_W_T_C + tid] = t;
-        st[ST_C_T_W + tid] = sh->Tinv[tid];
-        if (sh->improved) st[ST_BEST_T + tid] = t;
+        st[ST_C_T_W + tid] = ti;
+        if (improved) st[ST_BEST_T + tid] = t;
         if (hist_row != nullptr) hist_row[PICP_H_T + tid] = t;
     } else if (tid < 22) {
         if (hist_row != nullptr) hist_row[PICP_H_DX + (tid - 16)] = sh->dx[tid - 16];
-    } else if (tid == 22) {
-        st[ST_THR] = sh->thr;
-        st[ST_LAMBDA] = sh->lam;
-        st[ST_ERR_PREV] = sh->error;
-        st[ST_MEAN_SLOPE] = sh->mean_slope;
-        st[ST_SIGMA_SLOPE] = sh->sigma_slope;
-        st[ST_STUCK] = sh->stuck;
-        st[ST_FLICKER] = sh->flicker;
-        st[ST_IT] = (double)sh->it;
-        st[ST_STOP] = sh->stop;
+    } else if (tid == 64) {
+        st[ST_THR] = mine.thr;
+        st[ST_LAMBDA] = mine.lam;
+        st[ST_ERR_PREV] = mine.error;
+        st[ST_MEAN_SLOPE] = mine.mean_slope;
+        st[ST_SIGMA_SLOPE] = mine.sigma_slope;
+        st[ST_STUCK] = mine.stuck;
+        st[ST_FLICKER] = mine.flicker;
+        st[ST_IT] = (double)mine.it;
+        st[ST_STOP] = mine.stop;
         st[ST_MODE] = 0.0;
-        if (sh->ring_slot >= 0) st[ST_RING + sh->ring_slot] = sh->slope;
-        if (sh->improved) {
-            st[ST_BEST_ERR] = sh->error;
-            st[ST_BEST_IT] = (double)(sh->it - 1);
+        if (mine.ring_slot >= 0) st[ST_RING + mine.ring_slot] = mine.slope;
+        if (mine.improved) {
+            st[ST_BEST_ERR] = mine.error;
+            st[ST_BEST_IT] = (double)(mine.it - 1);
         }
-    } else if (tid == 23 && hist_row != nullptr) {
-        hist_row[PICP_H_ERROR] = sh->error;
-        hist_row[PICP_H_NUM_INLIERS] = sh->n_inliers;
-        hist_row[PICP_H_KERNEL_THR] = sh->thr;
-        hist_row[PICP_H_DAMPING] = sh->lam;
-        hist_row[PICP_H_N_INSIDE] = s1[S1_N_INSIDE];
-        hist_row[PICP_H_DONE] = sh->done;
-        hist_row[PICP_H_N_STAGE1] = s1[S1_COUNT];
-        hist_row[PICP_H_N_STAGE2] = sh->n_stage2;
-        hist_row[PICP_H_USED_STAGE2] = sh->used_stage2;
-        hist_row[PICP_H_MEAN_STAGE1] = sh->mean_stage1;
+        if (hist_row != nullptr) {
+            const double n_in = s1[S1_N_INSIDE], n_s1 = s1[S1_COUNT];
+            hist_row[PICP_H_ERROR] = mine.error;
+            hist_row[PICP_H_NUM_INLIERS] = mine.n_inliers;
+            hist_row[PICP_H_KERNEL_THR] = mine.thr;
+            hist_row[PICP_H_DAMPING] = mine.lam;
+            hist_row[PICP_H_N_INSIDE] = n_in;
+            hist_row[PICP_H_DONE] = mine.done;
+            hist_row[PICP_H_N_STAGE1] = n_s1;
+            hist_row[PICP_H_N_STAGE2] = mine.n_stage2;
+            hist_row[PICP_H_USED_STAGE2] = mine.used_stage2;
+            hist_row[PICP_H_MEAN_STAGE1] = mine.mean_stage1;
+        }
     }
     __syncthreads();
+#ifdef PICP_STAMPS
+    if (tid == 0 && blockIdx.x == 0 && sh->it == 6)
+        printf("solve_step: elimination done at %.2f, pose product at %.2f, pose wave %.2f us, schedule chain done at %.2f, barrier passed at %.2f, end %.2f\n",
+               (sh->t[4] - sh->t[0]) * 0.01, (sh->t[5] - sh->t[0]) * 0.01, (sh->t[1] - sh->t[0]) * 0.01, (sh->t[2] - sh->t[0]) * 0.01, (sh->t[3] - sh->t[0]) * 0.01,
+               (__builtin_amdgcn_s_memrealtime() - sh->t[0]) * 0.01);
+#endif
     return true;
 }
 

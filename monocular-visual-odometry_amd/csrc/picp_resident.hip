@@ -319,7 +319,17 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     __syncthreads();
 
     unsigned epoch = 0;
+#ifdef PICP_STAMPS
+    // Diagnostic build only: clock stamps of workgroup 0 at the segment boundaries of an iteration,
+    // left in the unused tail of the history row (entries 74 .. 79, microseconds since the iteration
+    // began: stage 1, its workgroup sum, its exchange, stage 2, its workgroup sum, its exchange).
+    unsigned long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+#define PICP_STAMP(k) stamp[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define PICP_STAMP(k)
+#endif
     while (st[ST_STOP] == 0.0) {
+        PICP_STAMP(0);
         double T[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) T[i] = uniform(st[ST_C_T_W + i]);
@@ -339,14 +349,17 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
                     kept[(r * 2 + 1) * NTR + threadIdx.x] = keep[1];
                 }
             }
+        PICP_STAMP(1);
         {
             const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
             const double tot = block_sum<3, NTR, false>(vals, lds);
+            PICP_STAMP(2);
             double g = tot;
             if (gridDim.x > 1 && !grid_total<3, 2>(tot, g, gx, epoch, lds_fold, &flag)) return;
             if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < 3) ? g : 0.0;
             __syncthreads();
         }
+        PICP_STAMP(3);
         const double n1 = s1[S1_COUNT]; // identical in every workgroup, so the branch below is grid-uniform
         if (n1 != 0.0) {
             const double mean = uniform(s1[S1_SUM_CHI] / n1); // np.mean, src/ProjectiveICP.py:301
@@ -367,9 +380,11 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
                                               muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], s);
                     }
                 }
+            PICP_STAMP(4);
             double vals[S2_USED];
             pack_sets(s, vals);
             const double tot = block_sum<S2_USED, NTR, false>(vals, lds);
+            PICP_STAMP(5);
             double g = 0.0;
             if (!grid_total<S2_USED, 16>(tot, g, gx, epoch, lds_fold, &flag)) return;
             if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = (threadIdx.x < S2_USED) ? g : 0.0;
@@ -378,9 +393,14 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
             if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = 0.0; // :300
             __syncthreads();
         }
+        PICP_STAMP(6);
 
         const bool record = (blockIdx.x == 0 && hist != nullptr && it < hist_rows);
         const bool advanced = solve_step(st, s1, s2, sc, record ? row : nullptr, &sh);
+#ifdef PICP_STAMPS
+        if (record && threadIdx.x < 6) row[74 + threadIdx.x] = (double)(stamp[threadIdx.x + 1] - stamp[0]) * 0.01;
+        __syncthreads();
+#endif
         if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
             hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
     }
