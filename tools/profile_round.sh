@@ -1,17 +1,24 @@
 #!/bin/bash
 # Collects the round's evidence on a GPU box, into gpurun_out/<tag>_*:
-#   tools/profile_round.sh r01d
-# a plain bench line (with the CPU baseline), a kernel trace with statistics of the same command, and
-# the two HBM-traffic counter passes (each in a run of its own, without any other tracing).
-set -e
+#   tools/profile_round.sh r02a [loop|batched|assoc ...]
+# per configuration: a plain bench line (with the CPU baseline), a kernel trace with statistics of the
+# same command, and the counter passes (HBM traffic, SQ instruction mix), each in a run of its own
+# without any other tracing.  profiles/summarize.py turns the directories into the files kept under profiles/.
 TAG=${1:-rXX}
+shift
+CONFIGS=${@:-loop}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write
-timeout -k 10 300 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-large-scan"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats -- python3 bench.py $ARGS > gpurun_out/${TAG}_stats.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${TAG}_fetch -- python3 bench.py $ARGS > gpurun_out/${TAG}_fetch.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${TAG}_write -- python3 bench.py $ARGS > gpurun_out/${TAG}_write.log 2>&1
-echo done
+for CFG in $CONFIGS; do
+  P=gpurun_out/${TAG}_${CFG}
+  rm -rf ${P}_stats ${P}_fetch ${P}_write ${P}_sq
+  timeout -k 10 400 python3 bench.py --config $CFG > ${P}_bench.json 2> ${P}_bench.err || { echo "bench $CFG failed"; exit 1; }
+  ARGS="--config $CFG --steps 10 --warmup 2 --no-cpu-baseline --no-large-scan"
+  [ "$CFG" = assoc ] && ARGS="--config $CFG --steps 4 --warmup 1 --no-cpu-baseline"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d ${P}_stats -- python3 bench.py $ARGS > ${P}_stats.log 2>&1 || { echo "trace $CFG failed"; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d ${P}_sq -- python3 bench.py $ARGS > ${P}_sq.log 2>&1 || { echo "sq $CFG failed"; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d ${P}_fetch -- python3 bench.py $ARGS > ${P}_fetch.log 2>&1 || { echo "fetch $CFG failed"; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d ${P}_write -- python3 bench.py $ARGS > ${P}_write.log 2>&1 || { echo "write $CFG failed"; exit 1; }
+  echo "$CFG done"
+done
