@@ -319,7 +319,8 @@ int picp_associate(picp_ctx* ctx, const double* app1, int64_t N1, const double* 
  * an open-addressing table keyed by a hash of the descriptor values, each query row runs the full
  * comparison only against its bucket, matches are emitted in increasing set-2 row.  mode 0 (default):
  * the join for large inputs (N1 * N2 >= 4e9), the scan otherwise.  The join gives up on inputs with
- * long runs of equal rows (more than 32 equal set-2 rows for one query row) and the scan is run
+ * long runs of equal rows (more than 32 equal set-2 rows for one query row), and does not take
+ * descriptors of more than 23 components (a workgroup's rows are staged in LDS); the scan is run
  * instead; picp_association_fallbacks counts how often. */
 int picp_set_association_mode(picp_ctx* ctx, int32_t mode);
 int picp_association_fallbacks(picp_ctx* ctx);

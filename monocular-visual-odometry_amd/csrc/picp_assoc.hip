@@ -150,13 +150,41 @@ __device__ __forceinline__ bool row_hash(const double* __restrict__ row, int D, 
     return ok;
 }
 
+// Brings the workgroup's rows [row0, row0 + rows) of a row-major descriptor array into LDS with
+// coalesced loads (consecutive lanes read consecutive 8-byte words; a lane reading its own row
+// straight from memory would touch a different cache line in every lane, D times over).  Rows are
+// DS = D | 1 doubles apart in LDS: an odd stride in doubles puts the 32 lanes of an LDS access
+// group on different banks when each lane then walks its own row.  Ends with a barrier.
+__device__ __forceinline__ void stage_rows(const double* __restrict__ app, int64_t row0, int rows, int D, int DS,
+                                           double* lds) {
+    const double* src = app + row0 * D;
+    const int n = rows * D;
+    int r = threadIdx.x / D, c = threadIdx.x % D;
+    const int dr = ANT / D, dc = ANT % D;
+    for (int e = threadIdx.x; e < n; e += ANT) {
+        lds[r * DS + c] = src[e];
+        r += dr;
+        c += dc;
+        if (c >= D) {
+            c -= D;
+            r += 1;
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(ANT) void hash_build_kernel(const double* __restrict__ app2, int64_t N2, int D,
                                                          unsigned long long* __restrict__ table, uint64_t mask,
                                                          int* __restrict__ flag) {
-    const int64_t j = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    extern __shared__ double rows_lds[];
+    const int DS = D | 1;
+    const int64_t row0 = (int64_t)blockIdx.x * ANT;
+    const int64_t left = N2 - row0;
+    stage_rows(app2, row0, left < ANT ? (int)left : ANT, D, DS, rows_lds);
+    const int64_t j = row0 + threadIdx.x;
     if (j >= N2) return;
     uint64_t h;
-    if (!row_hash(app2 + j * D, D, &h)) return;
+    if (!row_hash(rows_lds + threadIdx.x * DS, D, &h)) return;
     const unsigned long long entry = ((h >> 32) << 32) | (unsigned long long)(j + 1);
     uint64_t slot = h & mask;
     for (int probe = 0; probe < HASH_MAX_PROBE; ++probe) {
@@ -164,6 +192,24 @@ __global__ __launch_bounds__(ANT) void hash_build_kernel(const double* __restric
         slot = (slot + 1) & mask;
     }
     atomicExch(flag, 1);
+}
+
+// rows_equal for a query row held in LDS against a row of set 2 in memory.  WIDE: the rows of set 2
+// are read with 16-byte loads (D even and the array 16-byte aligned, so every row is), half as many
+// requests to what is a random cache line per query.
+template <bool WIDE>
+__device__ __forceinline__ bool row_equals_staged(const double* q, const double* __restrict__ b, int D) {
+    bool eq = true;
+    if (WIDE) {
+        const double2* b2 = reinterpret_cast<const double2*>(b);
+        for (int d = 0; d < D / 2; ++d) {
+            const double2 v = b2[d];
+            eq = eq && (q[2 * d] == v.x) && (q[2 * d + 1] == v.y);
+        }
+    } else {
+        for (int d = 0; d < D; ++d) eq = eq && (q[d] == b[d]);
+    }
+    return eq;
 }
 
 // Walks query row i's probe sequence; calls match(j) for every equal row j of set 2.
@@ -186,22 +232,97 @@ __device__ __forceinline__ bool hash_walk(const double* __restrict__ q, const do
     return false;
 }
 
+// The queries of a wave are verified against their candidate rows of set 2 together: a candidate row
+// is a random 80-byte piece of memory, and a lane that reads its own candidate with D (or D/2) loads
+// makes the wave request every one of 64 scattered cache lines D times over.  Here a row is read by a
+// group of P consecutive lanes, one 8- or 16-byte part each (P = D, or D/2 when WIDE), so one load
+// instruction fetches 64/P whole rows and every cache line is requested once; the parts' comparisons
+// are combined with a ballot.  cand: this lane's candidate row or -1; q_wave: the wave's 64 query
+// rows in LDS (row stride DS).  Returns whether this lane's candidate equals its query row.
+template <bool WIDE>
+__device__ __forceinline__ bool verify_candidates(int64_t cand, const double* q_wave, int DS,
+                                                  const double* __restrict__ app2, int D) {
+    const int lane = threadIdx.x & 63;
+    const int P = WIDE ? D / 2 : D;  // lanes per row
+    const int G = 64 / P;            // rows per load instruction
+    const int g = lane / P, part = lane - g * P;
+    const unsigned long long want = __ballot(cand >= 0);
+    bool equal = false;
+    for (int base = 0; base < 64; base += G) {
+        const unsigned long long chunk = (G >= 64) ? ~0ull : (((1ull << G) - 1ull) << base);
+        if ((want & chunk) == 0ull) continue; // uniform: no candidate among these queries
+        const int ql = base + g;              // the query this lane helps with
+        const int src = ql < 64 ? ql : 63;
+        const int64_t j = __shfl(cand, src, 64);
+        bool part_equal = true;
+        const bool active = (g < G) && (ql < 64) && (j >= 0);
+        if (active) {
+            const double* qrow = q_wave + src * DS;
+            if (WIDE) {
+                const double2 v = reinterpret_cast<const double2*>(app2 + j * D)[part];
+                part_equal = (qrow[2 * part] == v.x) && (qrow[2 * part + 1] == v.y);
+            } else {
+                part_equal = (qrow[part] == app2[j * D + part]);
+            }
+        }
+        // a query's row is equal when none of its P lanes saw a difference
+        const unsigned long long differs = __ballot(active && !part_equal);
+        const int mine = lane - base; // this lane's place among the chunk's queries
+        if (mine >= 0 && mine < G && cand >= 0) {
+            const unsigned long long group = ((P >= 64) ? ~0ull : ((1ull << P) - 1ull)) << (mine * P);
+            equal = (differs & group) == 0ull;
+        }
+    }
+    return equal;
+}
+
+template <bool WIDE>
 __global__ __launch_bounds__(ANT) void hash_count_kernel(const double* __restrict__ app1, int64_t N1,
                                                          const double* __restrict__ app2, int D,
                                                          const unsigned long long* __restrict__ table, uint64_t mask,
                                                          int64_t* __restrict__ count, int64_t* __restrict__ first,
                                                          int* __restrict__ flag) {
-    const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
-    if (i >= N1) return;
+    extern __shared__ double rows_lds[];
+    const int DS = D | 1;
+    const int64_t row0 = (int64_t)blockIdx.x * ANT;
+    const int64_t left = N1 - row0;
+    stage_rows(app1, row0, left < ANT ? (int)left : ANT, D, DS, rows_lds);
+    const int64_t i = row0 + threadIdx.x;
+    const double* q = rows_lds + threadIdx.x * DS;
+    const double* q_wave = rows_lds + (threadIdx.x & ~63) * DS;
     int64_t cnt = 0, fst = -1;
-    uint64_t h;
-    if (row_hash(app1 + i * D, D, &h)) {
-        const bool complete = hash_walk(app1 + i * D, app2, D, table, mask, h, [&](int64_t j) {
-            fst = (cnt == 0 || j < fst) ? j : fst;
-            cnt += 1;
-        });
-        if (!complete || cnt > HASH_MAX_DUP) atomicExch(flag, 1);
+    uint64_t h = 0;
+    // every lane of the wave stays in the walk (the verification is a wave-wide step); lanes without
+    // a query row, or whose row holds a NaN (equal to nothing), are finished from the start
+    bool walking = (i < N1) && row_hash(q, D, &h);
+    const unsigned long long tag = h >> 32;
+    uint64_t slot = h & mask;
+    int probe = 0;
+    bool complete = true;
+    while (__ballot(walking) != 0ull) {
+        int64_t cand = -1;
+        if (walking) {
+            const unsigned long long e = table[slot];
+            if (e == 0ull) {
+                walking = false;
+            } else {
+                if ((e >> 32) == tag) cand = (int64_t)(e & 0xffffffffull) - 1;
+                slot = (slot + 1) & mask;
+                if (++probe >= HASH_MAX_PROBE) {
+                    walking = false;
+                    complete = false;
+                }
+            }
+        }
+        if (__ballot(cand >= 0) != 0ull) {
+            if (verify_candidates<WIDE>(cand, q_wave, DS, app2, D)) {
+                fst = (cnt == 0 || cand < fst) ? cand : fst;
+                cnt += 1;
+            }
+        }
     }
+    if (i >= N1) return;
+    if (!complete || cnt > HASH_MAX_DUP) atomicExch(flag, 1);
     count[i] = cnt;
     first[i] = fst;
 }
@@ -446,9 +567,12 @@ static int associate_pass(picp_ctx* ctx, bool hashed, const double* app1, int64_
         mask = entries - 1;
         flag = reinterpret_cast<int*>(ctx->assoc_table + entries);
         PICP_HIP_CHECK(hipMemsetAsync(ctx->assoc_table, 0, sizeof(unsigned long long) * (entries + 1), s));
-        hipLaunchKernelGGL(hash_build_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, D,
-                           ctx->assoc_table, mask, flag);
-        hipLaunchKernelGGL(hash_count_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, D,
+        const unsigned stage_bytes = (unsigned)(sizeof(double) * ANT * (size_t)(D | 1)); // the workgroup's rows in LDS
+        hipLaunchKernelGGL(hash_build_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), stage_bytes, s, app2, N2,
+                           D, ctx->assoc_table, mask, flag);
+        const bool wide = (D % 2 == 0) && ((reinterpret_cast<uintptr_t>(app2) & 15u) == 0);
+        auto count_kernel = wide ? hash_count_kernel<true> : hash_count_kernel<false>;
+        hipLaunchKernelGGL(count_kernel, dim3(grid1), dim3(ANT), stage_bytes, s, app1, N1, app2, D,
                            (const unsigned long long*)ctx->assoc_table, mask, ctx->assoc_count, ctx->assoc_first, flag);
     } else {
         hipLaunchKernelGGL(assoc_keys_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, D,
@@ -516,7 +640,10 @@ int picp_associate(picp_ctx* ctx, const double* app1, int64_t N1, const double* 
     // pairs per second; the join costs a few tens of microseconds of launches plus ~1 ns per row).
     const bool fits = N2 < (int64_t)0xfffffffe; // table entries hold 32-bit row numbers
     PICP_REQUIRE(!(ctx->assoc_mode == 2 && !fits), "picp_associate: the hash join holds 32-bit row numbers");
-    const bool hashed = ctx->assoc_mode == 2 || (ctx->assoc_mode == 0 && fits && (double)N1 * (double)N2 >= 4.0e9);
+    const bool stageable = (size_t)ANT * (size_t)(D | 1) * sizeof(double) <= 48 * 1024; // a workgroup's rows in LDS (D <= 23)
+    if (ctx->assoc_mode == 2 && !stageable) ctx->assoc_hash_fallbacks += 1; // wider descriptors: the scan has no limit
+    const bool hashed = stageable && (ctx->assoc_mode == 2 ||
+                                      (ctx->assoc_mode == 0 && fits && (double)N1 * (double)N2 >= 4.0e9));
     bool retry = false;
     if (int rc = associate_pass(ctx, hashed, app1, N1, app2, N2, (int)D, idx1, idx2, capacity, count, &retry)) return rc;
     if (!retry) return PICP_OK;

@@ -368,6 +368,25 @@ def test_association_random_collisions(ctx, assoc_mode):
         assert np.array_equal(i1.cpu().numpy(), r1) and np.array_equal(i2.cpu().numpy(), r2), (k, D, n1, n2)
 
 
+def test_association_wide_and_odd_descriptors(ctx, assoc_mode):
+    """Descriptor widths around the hash join's staging (odd widths and unaligned views take 8-byte
+    loads; beyond 23 components the join hands over to the scan): the pair list of the oracle."""
+    rng = np.random.default_rng(41)
+    before = ctx.association_fallbacks()
+    for D in (2, 7, 10, 22, 23, 24, 40):
+        app2 = rng.integers(-1, 2, (3000, D)).astype(np.float64)
+        app2[:, 0] = rng.integers(0, 400, 3000)
+        app1 = app2[rng.integers(0, 3000, 2049)].copy()
+        app1[::5, D - 1] += 0.5                                   # differ only in the last component
+        r1, r2 = po.associate(app1, app2)
+        d2 = ctx.to_device(np.concatenate([np.zeros((1, D)), app2]))[1:]      # a view that starts 8 * D bytes in
+        for second in (ctx.to_device(app2), d2):
+            i1, i2 = ctx.associate(ctx.to_device(app1), second)
+            assert np.array_equal(i1.cpu().numpy(), r1) and np.array_equal(i2.cpu().numpy(), r2), D
+    if assoc_mode == "hash":
+        assert ctx.association_fallbacks() == before + 4          # D = 24 and 40, two calls each
+
+
 @pytest.mark.parametrize("M", [1 << 21, 1_500_001, 1 << 20, 700_001, 300_001, 70_000])
 def test_large_loop_against_oracle(ctx, loop_path, M):
     """Up to 2^21 correspondences, 6 iterations: counts exact, H/b/T within 1e-9 of the numpy oracle.
