@@ -108,8 +108,7 @@ class ProjectiveICP:
     def update(self, frame_index):
         """One frame (src/ProjectiveICP.py:89-151): ICP of the next measurement against the map,
         then triangulation of the frame-to-frame matches and map growth."""
-        if self.__save_results or self.__save_icp_plots:
-            os.makedirs(f'outputs/frame_{frame_index:02d}', exist_ok=True)
+        os.makedirs(f'outputs/frame_{frame_index:02d}', exist_ok=True)          # unconditionally, as the reference (:90)
         current_measurement = self.__data.get_measurements_data(frame_index)
         next_measurement = self.__data.get_measurements_data(frame_index + 1)
 

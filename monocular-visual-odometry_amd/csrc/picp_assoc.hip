@@ -515,7 +515,7 @@ static int ensure_assoc_workspace(picp_ctx* ctx, int64_t N1, int64_t N2) {
         PICP_HIP_CHECK(hipMalloc(&ctx->assoc_blocksum, sizeof(int64_t) * (nb + 1)));
         ctx->assoc_cap = cap;
     }
-    if (N2 > ctx->assoc_key_cap) {
+    if (N2 + 16 > ctx->assoc_key_cap) { // the scan prefetches up to 15 keys past the last one
         if (ctx->assoc_key) (void)hipFree(ctx->assoc_key);
         ctx->assoc_key = nullptr;
         ctx->assoc_key_cap = 0;

@@ -41,6 +41,8 @@ struct picp_ctx {
     int resident_aborts;           // launches abandoned so far (each was repeated with the streaming kernels)
     int resident_clean_grid;       // exchange slots hold sentinels for launches of up to this many workgroups
     int resident_last_grid;        // workgroups of the last launch
+    int abort_streak;              // consecutive single-launch loops that gave up
+    int single_launch_holdoff;     // picp_run calls that still go straight to the stage launches after a streak
     int64_t persistent_limit;      // largest M the streaming single-launch loop is used for (0: never)
     hipEvent_t loop_done;          // recorded behind a single-launch loop; the host waits for it, not for the stream
     hipEvent_t slot_done[PICP_ASYNC_SLOTS]; // the same for loops enqueued with picp_run_enqueue, one per slot

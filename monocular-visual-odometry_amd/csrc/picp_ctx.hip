@@ -120,8 +120,12 @@ int picp_destroy(picp_ctx* ctx) {
 
 int picp_set_stream(picp_ctx* ctx, void* stream) {
     PICP_REQUIRE(ctx != nullptr, "picp_set_stream: null ctx");
+    if (ctx->stream == static_cast<hipStream_t>(stream)) return PICP_OK;
+    // A refill of the exchange slots may still be pending on the old stream; nothing orders it with work on
+    // the new one, and a late refill would wipe records of a loop that runs there.  Wait for it.
+    DeviceGuard g(ctx->device);
+    PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->stream = static_cast<hipStream_t>(stream);
-    ctx->resident_clean_grid = 0; // slot refills enqueued on the old stream are not ordered with the new one
     return PICP_OK;
 }
 

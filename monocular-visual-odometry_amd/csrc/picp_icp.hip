@@ -569,31 +569,47 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
     if (int rc = check_pose(w_T_c0_host)) return rc;
     if (int rc = check_corr(u, v, x, y, z, M)) return rc;
     DeviceGuard g(ctx->device);
+    // A single-launch loop that gives up (device shared with other work) has burnt its whole bounded
+    // wait, a few hundred milliseconds, before the stage launches take over.  After three give-ups in
+    // a row the single launches are left out for a number of calls (32, doubling with every further
+    // give-up, at most 1 024), then tried again; one completed loop clears the streak.
+    const bool single_launch = (ctx->single_launch_holdoff == 0);
+    if (!single_launch) ctx->single_launch_holdoff -= 1;
+    auto gave_up = [&]() {
+        ctx->resident_aborts += 1;
+        ctx->abort_streak += 1;
+        if (ctx->abort_streak >= 3) {
+            const int shift = ctx->abort_streak - 3 < 5 ? ctx->abort_streak - 3 : 5;
+            ctx->single_launch_holdoff = 32 << shift;
+        }
+    };
     // Inputs that fit the register files run the whole loop in one launch (picp_resident.hip).
-    if (M > 0 && M <= resident_capacity(ctx) && sched->num_iterations > 0) {
+    if (single_launch && M > 0 && M <= resident_capacity(ctx) && sched->num_iterations > 0) {
         if (int rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
                                       ctx->pinned, nullptr, nullptr))
             return rc;
         if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
         if (ctx->pinned[ST_STOP] != 0.0) {
+            ctx->abort_streak = 0;
             result_from_state(ctx->pinned, w_T_c0_host, result);
             return PICP_OK;
         }
         // the launch was abandoned at a grid-wide wait (device shared with other work): start over
-        ctx->resident_aborts += 1;
+        gave_up();
     }
     // Larger inputs: the same single launch with the arrays streamed from memory every iteration.
-    if (M > resident_capacity(ctx) && ctx->resident_limit > 0 && M <= ctx->persistent_limit &&
+    if (single_launch && M > resident_capacity(ctx) && ctx->resident_limit > 0 && M <= ctx->persistent_limit &&
         sched->num_iterations > 0 && aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z)) {
         if (int rc = enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
                                         ctx->pinned, nullptr, nullptr))
             return rc;
         if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
         if (ctx->pinned[ST_STOP] != 0.0) {
+            ctx->abort_streak = 0;
             result_from_state(ctx->pinned, w_T_c0_host, result);
             return PICP_OK;
         }
-        ctx->resident_aborts += 1;
+        gave_up();
     }
     if (int rc = picp_state_init(ctx, state, w_T_c0_host, sched)) return rc;
     // Rounds of {stage 1, stage 2, solve} are enqueued in chunks; between chunks the stop flag is
