@@ -125,7 +125,8 @@ def committed_counters(pattern, kernel):
     matches `pattern` (profiles/summarize.py writes them).  Hardware counters cannot be read from inside
     the measured process, so these come from separate --pmc runs of this same command, kept under
     profiles/; returns (values dict, file) or (None, None)."""
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+    paths = [q for pat in pattern.split("|") for q in glob.glob(os.path.join(ROOT, "profiles", pat))]
+    for path in sorted(paths, key=os.path.basename, reverse=True):
         with open(path) as fh:
             k = json.load(fh)["kernels"]
         for name, v in k.items():
@@ -249,7 +250,7 @@ def bench_loop(args):
     L = pkg._lib
     ctx = pkg.get_context(local_rank)
     if single_device and world > 1:
-        ctx.set_grid_limit(240 // world)
+        ctx.set_grid_limit(192 // world)
 
     M = args.corr or ((1 << 20) if world == 1 else (1 << 26))
     lo, hi = pkg.sharded.shard_bounds(M, rank, world)
@@ -260,9 +261,12 @@ def bench_loop(args):
 
     plan = ctx.plan(corr, cam, sched) if world == 1 else None     # picp_run with its arguments marshalled once
 
+    stage_set = []
+
     def step_stages(mode):
-        stages = pkg.sharded.HipStages(ctx, corr, pose0, cam, sched, want_history=False)
-        res, _ = pkg.sharded.run_sharded(stages, ITERATIONS, disable_stop=True, native=(mode == "rccl"))
+        if not stage_set:                                       # state block and exchange records: once, not per step
+            stage_set.append(pkg.sharded.HipStages(ctx, corr, pose0, cam, sched, want_history=False))
+        res, _ = pkg.sharded.run_sharded(stage_set[0], ITERATIONS, disable_stop=True, native=(mode == "rccl"))
         return res
 
     def step_peer():
@@ -357,9 +361,9 @@ def bench_loop(args):
                             "40 B passes) against HBM, as the metric asks; the kernel itself reads each array once per "
                             "launch (hbm_utilisation_real) and is bound as real_bound says (valu)"}
             if M == (1 << 20):
-                tr, traffic_source = committed_counters("r*_pmc_traffic_2p20*.json", "icp_resident_kernel")
+                tr, traffic_source = committed_counters("r*_pmc_traffic_loop*.json|r*_pmc_traffic_2p20*.json", "icp_resident_kernel")
                 traffic = tr["hbm_bytes_per_launch"] if tr else None
-                sq, sq_src = committed_counters("r*_pmc_sq_2p20*.json", "icp_resident_kernel")
+                sq, sq_src = committed_counters("r*_pmc_sq_loop*.json|r*_pmc_sq_2p20*.json", "icp_resident_kernel")
                 roof["valu"] = valu_block(sq, sq_src, run_mean_ms)
                 roof["traffic_note"] = "from the committed FETCH_SIZE/WRITE_SIZE passes of this command, not collected in this run"
         elif world == 1:

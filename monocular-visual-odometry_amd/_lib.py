@@ -26,6 +26,7 @@ H_N_INSIDE, H_DONE, H_N_STAGE1, H_N_STAGE2, H_USED_STAGE2, H_MEAN_STAGE1 = 20, 2
 H_DX, H_B, H_H = 26, 32, 38
 # state block layout (csrc/picp_device.h)
 ST_W_T_C, ST_C_T_W, ST_THR, ST_LAMBDA, ST_IT, ST_STOP = 0, 16, 32, 33, 39, 40
+ST_BEST_ERR, ST_BEST_IT, ST_BEST_T = 51, 52, 64
 
 LINEARIZE_OUT_DOUBLES = 48
 NOALLOC_MAX_CORRESPONDENCES = 1 << 32

@@ -4,7 +4,8 @@
 // iteration needs (src/ProjectiveICP.py:301 and :313-317) are then all-reduced over the ranks.
 // Here the collective is RCCL's ncclAllReduce enqueued on the same stream as the scan kernels, so
 // an iteration is one in-order chain
-//     stage 1 -> fold -> all-reduce(4 doubles) -> stage 2 -> fold -> all-reduce(32 doubles) -> solve
+//     stage 1 -> all-reduce(4 doubles) -> stage 2 -> all-reduce(32 doubles)
+// (each scan folds its own records, the solve step runs in the next stage 1's prologue: picp_icp.hip)
 // with no hop to another stream and back around each collective, and the host enqueues whole
 // rounds with one call.  RCCL is loaded at run time (dlopen), so the library itself does not
 // depend on it: single-GPU users never touch it.
@@ -146,17 +147,9 @@ int picp_sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const d
                         double* s1, double* s2, double* hist, int32_t hist_rows, int32_t rounds) {
     PICP_REQUIRE(ctx && state && cam && sched && s1 && s2, "picp_sharded_rounds: null argument");
     PICP_REQUIRE(rounds >= 0, "picp_sharded_rounds: negative number of rounds");
+    PICP_REQUIRE(M >= 0 && (M == 0 || (u && v && x && y && z)), "picp_sharded_rounds: bad correspondence arrays");
     DeviceGuard g(ctx->device);
-    for (int k = 0; k < rounds; ++k) {
-        if (int rc = picp_stage1(ctx, u, v, x, y, z, M, state, cam)) return rc;
-        if (int rc = picp_stage1_reduce(ctx, s1)) return rc;
-        if (int rc = allreduce_sum(ctx, s1, PICP_S1_DOUBLES)) return rc;
-        if (int rc = picp_stage2(ctx, u, v, x, y, z, M, state, cam, s1)) return rc;
-        if (int rc = picp_stage2_reduce(ctx, s2)) return rc;
-        if (int rc = allreduce_sum(ctx, s2, PICP_S2_DOUBLES)) return rc;
-        if (int rc = picp_solve(ctx, state, sched, s1, s2, hist, hist_rows)) return rc;
-    }
-    return PICP_OK;
+    return sharded_rounds(ctx, u, v, x, y, z, M, state, cam, sched, s1, s2, hist, (int)hist_rows, (int)rounds, allreduce_sum);
 }
 
 } // extern "C"

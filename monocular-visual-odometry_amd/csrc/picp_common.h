@@ -20,6 +20,7 @@ struct picp_ctx {
     int rows1, rows2; // rows written by the last stage-1 / stage-2 launch
     int stage2_reverse; // stage 2 walks the arrays against stage 1's direction: 1 always, 0 never, -1 by size
     double* scratch;  // small device scratch: state block + s1 + s2 + misc (see offsets below)
+    unsigned* arrive; // [2] arrival counters of the sharded rounds' scans (zero between launches)
     // association workspace, grown on demand
     int64_t* assoc_count;  // [cap] matches per query row
     int64_t* assoc_first;  // [cap] first matching row of set 2
@@ -70,6 +71,7 @@ enum : int {
     SCR_S1 = 128,                               // PICP_S1_DOUBLES
     SCR_S2 = 192,                               // PICP_S2_DOUBLES
     SCR_MISC = 256,                             // 64 doubles for tiny test kernels
+    SCR_STATE2 = 384,                           // second state block of the sharded rounds (PICP_STATE_DOUBLES)
     SCR_DOUBLES = 512,
 };
 enum : int { PINNED_DOUBLES = 4096, PINNED_SLOT0 = 2048, PINNED_SLOT_STRIDE = 128 }; // final states of enqueued loops
@@ -79,6 +81,9 @@ int hip_fail(hipError_t e, const char* what);
 
 // picp_icp.hip
 int noalloc_bind(picp_ctx* ctx);
+int sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
+                   int64_t M, double* state, const picp_camera* cam, const picp_schedule* sched, double* s1, double* s2,
+                   double* hist, int hist_rows, int rounds, int (*allreduce)(picp_ctx*, double*, size_t));
 
 // picp_resident.hip
 int64_t resident_capacity(const picp_ctx* ctx);

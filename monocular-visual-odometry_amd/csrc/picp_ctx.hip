@@ -68,6 +68,8 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     if (e == hipSuccess) e = hipMalloc(&ctx->scratch, sizeof(double) * SCR_DOUBLES);
     if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, sizeof(double) * PINNED_DOUBLES, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemset(ctx->scratch, 0, sizeof(double) * SCR_DOUBLES);
+    if (e == hipSuccess) e = hipMalloc(&ctx->arrive, sizeof(unsigned) * 64);
+    if (e == hipSuccess) e = hipMemset(ctx->arrive, 0, sizeof(unsigned) * 64);
     if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * 3 * PICP_S2_DOUBLES * ctx->num_cus);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->loop_done, hipEventDisableTiming);
     for (int k = 0; k < PICP_ASYNC_SLOTS && e == hipSuccess; ++k)
@@ -101,6 +103,7 @@ int picp_destroy(picp_ctx* ctx) {
     if (ctx->part1) (void)hipFree(ctx->part1);
     if (ctx->part2) (void)hipFree(ctx->part2);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->arrive) (void)hipFree(ctx->arrive);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->rslots) (void)hipFree(ctx->rslots);
     if (ctx->loop_done) (void)hipEventDestroy(ctx->loop_done);

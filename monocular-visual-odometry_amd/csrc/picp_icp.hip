@@ -148,6 +148,155 @@ __global__ __launch_bounds__(NT_SOLVE) void solve_kernel(double* __restrict__ st
         hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
 }
 
+// ---- sharded rounds: two launches per round ---------------------------------------------------
+// A round of a sharded run is  stage 1 -> all-reduce -> stage 2 -> all-reduce  and nothing else:
+//  * each scan folds its own per-workgroup records: a workgroup stores its record (write-through),
+//    waits for the stores, and takes a ticket from an arrival counter; the workgroup that draws the
+//    last ticket reads all records (in index order, so the sum does not depend on who was last) and
+//    leaves the shard's record where the all-reduce expects it -- no fold launch;
+//  * the solve step of round k runs in the prologue of round k+1's stage 1, in every workgroup alike
+//    (identical inputs, identical result; the first loads of the scan are already in flight), and
+//    workgroup 0 writes the new state block and the history row -- no solve launch.  The state
+//    alternates between two blocks, so no workgroup reads a block that another one is rewriting.
+// Only the last round of a call is followed by a solve launch, which leaves the caller's state
+// block complete.
+template <int NV, int NVW, int NT_>
+__device__ __forceinline__ void fold_by_last_arrival(double tot, double* __restrict__ part, unsigned* __restrict__ counter,
+                                                     double* __restrict__ out, double* lds /* NT_ */, int* lds_last) {
+    static_assert(NVW <= 64 && NT_ % NVW == 0, "the record is stored by the first wave");
+    const int G = gridDim.x;
+    const int tid = threadIdx.x;
+    if (tid < NVW)
+        __hip_atomic_store(part + (size_t)blockIdx.x * NVW + tid, (tid < NV) ? tot : 0.0, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record is in memory before the ticket is drawn
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *lds_last = (ticket == (unsigned)(G - 1)) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (*lds_last == 0) return;
+    constexpr int GR = NT_ / NVW; // row groups
+    const int col = tid % NVW, grp = tid / NVW;
+    double acc = 0.0;
+    for (int r = grp; r < G; r += GR)
+        acc += __hip_atomic_load(part + (size_t)r * NVW + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lds[tid] = acc;
+    __syncthreads();
+    if (tid < NVW) {
+        double t = 0.0;
+        for (int g = 0; g < GR; ++g) t += lds[g * NVW + tid];
+        out[tid] = t;
+    }
+    if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // for the next launch
+}
+
+template <int VEC, bool PINHOLE, int THREADS>
+__global__ __launch_bounds__(THREADS) void stage1_round_kernel(
+    const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ x, const double* __restrict__ y,
+    const double* __restrict__ z, int64_t M, const double* __restrict__ state_in, double* __restrict__ state_out,
+    picp_schedule sc, const double* __restrict__ s1_prev, const double* __restrict__ s2_prev, int do_solve,
+    double* __restrict__ hist, int hist_rows, CameraK cam, double* __restrict__ part, unsigned* __restrict__ counter,
+    double* __restrict__ s1_out) {
+    static_assert(THREADS >= 192, "solve_step needs three waves");
+    __shared__ double lds[THREADS];
+    __shared__ double st[PICP_STATE_DOUBLES];
+    __shared__ double s1[PICP_S1_DOUBLES];
+    __shared__ double s2[PICP_S2_DOUBLES];
+    __shared__ double row[PICP_HIST_STRIDE];
+    __shared__ StepShared sh;
+    __shared__ int last;
+    CorrStream<VEC, THREADS> stream;
+    stream.start(u, v, x, y, z, M); // first loads in flight before anything else
+    if (threadIdx.x < PICP_STATE_DOUBLES) st[threadIdx.x] = state_in[threadIdx.x];
+    if (do_solve) {
+        if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = s1_prev[threadIdx.x];
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + PICP_S2_DOUBLES) s2[threadIdx.x - 64] = s2_prev[threadIdx.x - 64];
+    }
+    __syncthreads();
+    if (do_solve) {
+        if (st[ST_STOP] == 0.0) { // the previous round's solve step (uniform over the grid)
+            const int it = (int)st[ST_IT];
+            const bool record = (blockIdx.x == 0 && hist != nullptr && it < hist_rows);
+            const bool advanced = solve_step(st, s1, s2, sc, record ? row : nullptr, &sh);
+            if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
+                hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
+        }
+        if (blockIdx.x == 0 && threadIdx.x < PICP_STATE_DOUBLES) state_out[threadIdx.x] = st[threadIdx.x];
+    }
+    if (st[ST_STOP] != 0.0) return;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = st[ST_C_T_W + i];
+    const double thr = st[ST_THR];
+    Stage1Sums s{0.0, 0u, 0u};
+    stream.run([&](double mu, double mv, double px, double py, double pz) {
+        stage1_point<PINHOLE>(T, cam, thr, mu, mv, px, py, pz, s);
+    });
+    const double vals[3] = {s.sum_chi, (double)s.n1, (double)s.n_inside};
+    const double tot = block_sum<3, THREADS>(vals, lds);
+    fold_by_last_arrival<3, PICP_S1_DOUBLES, THREADS>(tot, part, counter, s1_out, lds, &last);
+}
+
+template <int VEC, bool PINHOLE, bool REVERSE>
+__global__ __launch_bounds__(NT2) void stage2_round_kernel(const double* __restrict__ u, const double* __restrict__ v,
+                                                          const double* __restrict__ x, const double* __restrict__ y,
+                                                          const double* __restrict__ z, int64_t M,
+                                                          const double* __restrict__ state, CameraK cam,
+                                                          const double* __restrict__ s1g, double* __restrict__ part,
+                                                          unsigned* __restrict__ counter, double* __restrict__ s2_out) {
+    __shared__ double lds[NT2];
+    __shared__ int last;
+    CorrStream<VEC, NT2, REVERSE> stream;
+    stream.start(u, v, x, y, z, M);
+    if (state[ST_STOP] != 0.0) return;
+    const double n1 = s1g[S1_COUNT];
+    Stage2Sums s;
+    s.clear();
+    if (n1 != 0.0) { // else nothing survived stage 1 (src/ProjectiveICP.py:300): the sums are zero
+        const double mean = s1g[S1_SUM_CHI] / n1; // np.mean, :301
+        double T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = state[ST_C_T_W + i];
+        const double thr = state[ST_THR];
+        const bool all = (state[ST_MODE] != 0.0);
+        stream.run([&](double mu, double mv, double px, double py, double pz) {
+            stage2_point<PINHOLE>(T, cam, thr, mean, all, mu, mv, px, py, pz, s);
+        });
+    }
+    double vals[S2_USED];
+    pack_sets(s, vals);
+    const double tot = block_sum<S2_USED, NT2>(vals, lds);
+    fold_by_last_arrival<S2_USED, PICP_S2_DOUBLES, NT2>(tot, part, counter, s2_out, lds, &last);
+}
+
+// The solve step as a launch of its own, from reduced records, reading one state block and writing
+// another (or the same): closes the last round of a call.
+__global__ __launch_bounds__(256) void solve_round_kernel(const double* __restrict__ state_in, double* __restrict__ state_out,
+                                                         picp_schedule sc, const double* __restrict__ s1g,
+                                                         const double* __restrict__ s2g, double* __restrict__ hist,
+                                                         int hist_rows) {
+    __shared__ double st[PICP_STATE_DOUBLES];
+    __shared__ double s1[PICP_S1_DOUBLES];
+    __shared__ double s2[PICP_S2_DOUBLES];
+    __shared__ double row[PICP_HIST_STRIDE];
+    __shared__ StepShared sh;
+    if (threadIdx.x < PICP_STATE_DOUBLES) st[threadIdx.x] = state_in[threadIdx.x];
+    if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = s1g[threadIdx.x];
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + PICP_S2_DOUBLES) s2[threadIdx.x - 128] = s2g[threadIdx.x - 128];
+    __syncthreads();
+    if (st[ST_STOP] == 0.0) {
+        const int it = (int)st[ST_IT];
+        const bool record = (hist != nullptr && it < hist_rows);
+        const bool advanced = solve_step(st, s1, s2, sc, record ? row : nullptr, &sh);
+        if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
+            hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
+    }
+    if (threadIdx.x < PICP_STATE_DOUBLES) state_out[threadIdx.x] = st[threadIdx.x];
+}
+
 // ---- whole loop in one workgroup, one problem per workgroup -------------------------------------
 // Problems of any size: the correspondences are re-read (from cache) every iteration.  Problems
 // with a known bound on their size are held on chip instead (picp_resident.hip).
@@ -397,6 +546,43 @@ __global__ void linearize_decide_kernel(double* __restrict__ state, const double
         out[tid] = 0.0;
     }
     if (tid == 63) state[ST_STOP] = 1.0;
+}
+
+// One call's worth of sharded rounds with two launches per round (see stage1_round_kernel).
+// allreduce(buf, count): the caller's exchange, enqueued on the ctx's stream (a no-op for one shard).
+int sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
+                   int64_t M, double* state, const picp_camera* cam, const picp_schedule* sched, double* s1, double* s2,
+                   double* hist, int hist_rows, int rounds, int (*allreduce)(picp_ctx*, double*, size_t)) {
+    if (rounds <= 0) return PICP_OK;
+    const CameraK c = to_device_camera(cam);
+    const bool pin = is_pinhole(cam->K);
+    const bool vec = aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z);
+    const bool reverse = vec && stage2_reverse(ctx, M);
+    const int grid1 = grid_for(vec ? (M + 1) / 2 : M, NT2, ctx->max_blocks2 < ctx->max_blocks1 ? ctx->max_blocks2 : ctx->max_blocks1);
+    const int grid2 = grid_for(vec ? (M + 1) / 2 : M, NT2, ctx->max_blocks2);
+    auto k1 = vec ? (pin ? stage1_round_kernel<2, true, NT2> : stage1_round_kernel<2, false, NT2>)
+                  : (pin ? stage1_round_kernel<1, true, NT2> : stage1_round_kernel<1, false, NT2>);
+    auto k2 = vec ? (reverse ? (pin ? stage2_round_kernel<2, true, true> : stage2_round_kernel<2, false, true>)
+                             : (pin ? stage2_round_kernel<2, true, false> : stage2_round_kernel<2, false, false>))
+                  : (pin ? stage2_round_kernel<1, true, false> : stage2_round_kernel<1, false, false>);
+    double* other = ctx->scratch + SCR_STATE2; // the state alternates between the caller's block and this one
+    double* cur = state;
+    hipStream_t st = ctx->stream;
+    for (int k = 0; k < rounds; ++k) {
+        double* nxt = (cur == state) ? other : state;
+        hipLaunchKernelGGL(k1, dim3(grid1), dim3(NT2), 0, st, u, v, x, y, z, M, (const double*)cur, nxt, *sched,
+                           (const double*)s1, (const double*)s2, k > 0 ? 1 : 0, hist, hist_rows, c, ctx->part1,
+                           ctx->arrive, s1);
+        if (k > 0) cur = nxt;
+        if (int rc = allreduce(ctx, s1, PICP_S1_DOUBLES)) return rc;
+        hipLaunchKernelGGL(k2, dim3(grid2), dim3(NT2), 0, st, u, v, x, y, z, M, (const double*)cur, c, (const double*)s1,
+                           ctx->part2, ctx->arrive + 1, s2);
+        if (int rc = allreduce(ctx, s2, PICP_S2_DOUBLES)) return rc;
+    }
+    hipLaunchKernelGGL(solve_round_kernel, dim3(1), dim3(256), 0, st, (const double*)cur, state, *sched, (const double*)s1,
+                       (const double*)s2, hist, hist_rows);
+    PICP_HIP_CHECK(hipGetLastError());
+    return PICP_OK;
 }
 
 } // namespace picp

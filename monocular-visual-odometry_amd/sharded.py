@@ -53,6 +53,7 @@ class HipStages:
         self._corr_ptrs = [ctx.ptr(c) for c in corr]
 
     def state_init(self):
+        self._host_state = None
         check(self.ctx.lib.picp_state_init(self.ctx.handle, self.ctx.ptr(self.state),
                                            self.pose.ctypes.data_as(C.c_void_p), C.byref(self.sched)), "picp_state_init")
 
@@ -70,12 +71,14 @@ class HipStages:
         return self.s2
 
     def solve(self, s1, s2):
+        self._host_state = None
         check(self.ctx.lib.picp_solve(self.ctx.handle, self.ctx.ptr(self.state), C.byref(self.sched), self.ctx.ptr(s1),
                                       self.ctx.ptr(s2), self.ctx.ptr(self.hist), self.rows if self.hist is not None else 0),
               "picp_solve")
 
     def rounds(self, n):
         """Enqueues n rounds, the all-reduces included when the ctx has a communicator."""
+        self._host_state = None
         check(self.ctx.lib.picp_sharded_rounds(self.ctx.handle, *self._corr_ptrs, self.M, self.ctx.ptr(self.state),
                                                C.byref(self.cam), C.byref(self.sched), self.ctx.ptr(self.s1),
                                                self.ctx.ptr(self.s2), self.ctx.ptr(self.hist),
@@ -92,7 +95,9 @@ class HipStages:
         return self.comm_world >= 1
 
     def stopped(self):
-        return bool(self.state[_lib.ST_STOP].item() != 0.0)
+        """Reads the replicated state block back (one synchronising copy, kept for `finish`)."""
+        self._host_state = self.state.cpu().numpy()
+        return bool(self._host_state[_lib.ST_STOP] != 0.0)
 
     def state_checksum(self):
         """62-bit checksum of the replicated state block's bit patterns (a one-ulp difference in any of
@@ -104,6 +109,19 @@ class HipStages:
 
     def finish(self):
         res = _lib.ResultStruct()
+        h = getattr(self, "_host_state", None)
+        if h is not None and h[_lib.ST_STOP] != 0.0:
+            # the state read back by `stopped` is final: the best-iteration rule of picp_finish on it
+            # (src/ProjectiveICP.py:249-257), without a second synchronising copy
+            n_it = int(h[_lib.ST_IT])
+            valid = n_it > 0 and not (h[_lib.ST_BEST_ERR] > 5.0)
+            T = h[_lib.ST_BEST_T:_lib.ST_BEST_T + 16] if valid else self.pose
+            for i in range(16):
+                res.T[i] = float(T[i])
+            res.valid, res.num_iterations = int(valid), n_it
+            res.best_index, res.best_error = int(h[_lib.ST_BEST_IT]), float(h[_lib.ST_BEST_ERR])
+            hist = self.hist[:n_it].cpu().numpy() if self.hist is not None else None
+            return res, hist
         check(self.ctx.lib.picp_finish(self.ctx.handle, self.ctx.ptr(self.state), self.ctx.ptr(self.hist), self.rows,
                                        self.pose.ctypes.data_as(C.c_void_p), C.byref(res)), "picp_finish")
         hist = self.hist[: res.num_iterations].cpu().numpy() if self.hist is not None else None

@@ -19,12 +19,12 @@ sched = L.schedule_struct(20, 10, 1000, 10, 2000, 64, 1, 64, disable_stop=True)
 assert pkg.sharded.init_peer_exchange(ctx)          # one rank: the sharded single launch without peers
 for M in [int(a) for a in sys.argv[1:]] or [1 << 21, 1 << 23, 1 << 25]:
     corr = bench.device_problem(ctx, M, 0, M)
+    stages = pkg.sharded.HipStages(ctx, corr, np.eye(4), cam, sched, want_history=False)
     for name, limit, fn in (
             ("picp_run (single launch)", None, lambda: ctx.run(corr, np.eye(4), cam, sched, want_history=False)),
             ("picp_run_sharded, 1 rank", None, lambda: ctx.run_sharded(corr, np.eye(4), cam, sched, want_history=False)),
             ("picp_run (stage launches)", 0, lambda: ctx.run(corr, np.eye(4), cam, sched, want_history=False)),
-            ("run_sharded rounds, 1 rank", 0, lambda: pkg.sharded.run_sharded(
-                pkg.sharded.HipStages(ctx, corr, np.eye(4), cam, sched, want_history=False), 20, disable_stop=True))):
+            ("run_sharded rounds, 1 rank", 0, lambda: pkg.sharded.run_sharded(stages, 20, disable_stop=True))):
         ctx.set_resident_limit(limit)
         fn()
         torch.cuda.synchronize()
