@@ -223,32 +223,47 @@ __device__ __forceinline__ bool cross_total(double mine, double& out, const Peer
 // Stage 1 of one correspondence (as stage1_point) that also leaves what stage 2 needs of it in
 // `keep`: chi (NaN when the pair is outside the image or above the threshold, so that every later
 // comparison with it is false) and 1 / (K p)_z, the one division of the projection.
+// `ok`: the lane holds a correspondence in this place (a lane past the end of the input runs the same
+// arithmetic on a copy of another correspondence and counts nothing: no lane-dependent branch).
 template <bool PINHOLE>
 __device__ __forceinline__ void stage1_keep(const double* __restrict__ T, const CameraK& cam, double thr, double mu,
-                                            double mv, double x, double y, double z, Stage1Sums& s, double (&keep)[2]) {
+                                            double mv, double x, double y, double z, bool ok, Stage1Sums& s,
+                                            double (&keep)[2]) {
     const Projected p = project_point<PINHOLE>(T, cam, x, y, z);
     const double e0 = mu - p.u, e1 = mv - p.v;         // src/ProjectiveICP.py:333
     const double chi = chi_of(e0, e1);                 // :293
-    const bool in1 = p.inside && (chi <= thr);         // :290, :294
-    s.n_inside += p.inside ? 1u : 0u;
+    const bool inside = p.inside && ok;
+    const bool in1 = inside && (chi <= thr);           // :290, :294
+    s.n_inside += inside ? 1u : 0u;
     s.n1 += in1 ? 1u : 0u;
     s.sum_chi += in1 ? chi : 0.0;
     keep[0] = in1 ? chi : __builtin_nan("");
     keep[1] = p.zi;
 }
 
-// Stage 2 of a correspondence that stage 1 accepted, from the kept values: the camera-frame point,
-// K p and the pixel are formed again with the expressions of project_point and the kept
-// reciprocal (an accepted pair is finite and in the image, where the pinhole and the general
-// product with K agree and the reciprocal form of the division is the one project_point used).
+// Stage 2 of a correspondence from the values stage 1 kept: the camera-frame point, K p and the pixel
+// are formed again with the expressions of project_point and the kept reciprocal (an accepted pair is
+// finite and in the image, where the pinhole and the general product with K agree and the reciprocal
+// form of the division is the one project_point used).
+// Branch-free: every lane runs the arithmetic, and a lane whose pair is not in the inlier set
+// (`keep` false) has the point, the reciprocal and the residual replaced by zeros before they are
+// used, so that its Jacobian and all its products are exact zeros and its sums do not change.  With
+// the lane-dependent branch gone, the correspondences of a thread form one straight-line block and
+// the compiler interleaves their dependent chains; behind a branch per correspondence each chain ran
+// on its own, exposed to its full latency (measured: a wave alone on its SIMD needed 570 cycles per
+// correspondence for about 100 instructions).
 template <bool PINHOLE, bool HAVE_ZI = true>
 __device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const CameraK& cam, double mu, double mv,
-                                            double x, double y, double z, double chi, double zi, Stage2Sums& s) {
+                                            double x, double y, double z, double chi, double zi, bool keep,
+                                            Stage2Sums& s) {
 #pragma clang fp contract(off)
     Projected p;
     p.pcx = __builtin_fma(T[2], z, __builtin_fma(T[1], y, T[0] * x)) + T[3];
     p.pcy = __builtin_fma(T[6], z, __builtin_fma(T[5], y, T[4] * x)) + T[7];
     p.pcz = __builtin_fma(T[10], z, __builtin_fma(T[9], y, T[8] * x)) + T[11];
+    p.pcx = keep ? p.pcx : 0.0;
+    p.pcy = keep ? p.pcy : 0.0;
+    p.pcz = keep ? p.pcz : 0.0;
     if (PINHOLE) {
         p.h0 = __builtin_fma(cam.k[2], p.pcz, cam.k[0] * p.pcx);
         p.h1 = __builtin_fma(cam.k[5], p.pcz, cam.k[4] * p.pcy);
@@ -259,14 +274,17 @@ __device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const 
         p.h2 = __builtin_fma(cam.k[8], p.pcz, __builtin_fma(cam.k[7], p.pcy, cam.k[6] * p.pcx));
     }
     if (!HAVE_ZI) zi = 1.0 / p.h2; // the caller kept only chi
-    const double e0 = mu - div_with_recip(p.h0, p.h2, zi);
-    const double e1 = mv - div_with_recip(p.h1, p.h2, zi);
+    zi = keep ? zi : 0.0;
+    double e0 = mu - div_with_recip(p.h0, p.h2, zi);
+    double e1 = mv - div_with_recip(p.h1, p.h2, zi);
+    e0 = keep ? e0 : 0.0;
+    e1 = keep ? e1 : 0.0;
     p.zi = zi;
     double J0[6], J1[6];
     jacobian_rows<PINHOLE>(p, cam, J0, J1);
     s.S.add<PINHOLE>(J0, J1, e0, e1);
-    s.chi += chi;
-    s.n += 1u;
+    s.chi += keep ? chi : 0.0;
+    s.n += keep ? 1u : 0u;
 }
 
 template <int R, bool PINHOLE>
@@ -324,7 +342,12 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     // left in the unused tail of the history row (entries 74 .. 79, microseconds since the iteration
     // began: stage 1, its workgroup sum, its exchange, stage 2, its workgroup sum, its exchange).
     unsigned long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
-#define PICP_STAMP(k) stamp[k] = __builtin_amdgcn_s_memrealtime()
+    __shared__ unsigned long long wave_stamp[7][NTR / 64]; // the same boundaries as every wave of workgroup 0 sees them
+#define PICP_STAMP(k)                                                             \
+    {                                                                             \
+        stamp[k] = __builtin_amdgcn_s_memrealtime();                              \
+        if ((threadIdx.x & 63) == 0) wave_stamp[k][threadIdx.x >> 6] = stamp[k];  \
+    }
 #else
 #define PICP_STAMP(k)
 #endif
@@ -340,10 +363,10 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         Stage1Sums a{0.0, 0u, 0u};
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (r < mine) {
+            if (KEEP || r < mine) { // KEEP: no branch, the lanes past the end are masked inside
                 double keep[2];
                 stage1_keep<PINHOLE>(T, cam, thr, muv[(r * 2 + 0) * NTR + threadIdx.x],
-                                     muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], a, keep);
+                                     muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], r < mine, a, keep);
                 if (KEEP) {
                     kept[(r * 2 + 0) * NTR + threadIdx.x] = keep[0];
                     kept[(r * 2 + 1) * NTR + threadIdx.x] = keep[1];
@@ -367,14 +390,14 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
             s.clear();
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (r < mine) {
-                    if (KEEP) {
+                if (KEEP || r < mine) {
+                        if (KEEP) {
                         const double chi = kept[(r * 2 + 0) * NTR + threadIdx.x];
                         // NaN (rejected by stage 1) fails both tests; `all`: the stage-1 set, else chi < mean (:302)
-                        if ((chi <= thr) && (all || chi < mean))
-                            stage2_kept<PINHOLE>(T, cam, muv[(r * 2 + 0) * NTR + threadIdx.x],
-                                                 muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], chi,
-                                                 kept[(r * 2 + 1) * NTR + threadIdx.x], s);
+                        const bool in_set = (r < mine) && (chi <= thr) && (all || chi < mean);
+                        stage2_kept<PINHOLE>(T, cam, muv[(r * 2 + 0) * NTR + threadIdx.x],
+                                             muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], chi,
+                                             kept[(r * 2 + 1) * NTR + threadIdx.x], in_set, s);
                     } else {
                         stage2_point<PINHOLE>(T, cam, thr, mean, all, muv[(r * 2 + 0) * NTR + threadIdx.x],
                                               muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], s);
@@ -399,6 +422,13 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         const bool advanced = solve_step(st, s1, s2, sc, record ? row : nullptr, &sh);
 #ifdef PICP_STAMPS
         if (record && threadIdx.x < 6) row[74 + threadIdx.x] = (double)(stamp[threadIdx.x + 1] - stamp[0]) * 0.01;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && it == 6) {
+            for (int k = 1; k < 7; ++k) {
+                printf("boundary %d by wave:", k);
+                for (int w = 0; w < NTR / 64; ++w) printf(" %.2f", (double)(wave_stamp[k][w] - wave_stamp[0][0]) * 0.01);
+                printf("\n");
+            }
+        }
         __syncthreads();
 #endif
         if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
@@ -586,10 +616,10 @@ __global__ __launch_bounds__(NTB, (R <= BATCHED_THREE_PER_CU_MAX_R) ? 3 : 2) voi
         Stage1Sums a{0.0, 0u, 0u};
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (r < mine) {
+            if (r < mine) { // (branches kept here: the other workgroups of the CU cover a chain's latency)
                 double keep[2];
                 stage1_keep<PINHOLE>(T, cam, thr, muv[(r * 2 + 0) * NTB + threadIdx.x],
-                                     muv[(r * 2 + 1) * NTB + threadIdx.x], rx[r], ry[r], rz[r], a, keep);
+                                     muv[(r * 2 + 1) * NTB + threadIdx.x], rx[r], ry[r], rz[r], true, a, keep);
                 kept[(r * KS + 0) * NTB + threadIdx.x] = keep[0];
                 if (KS == 2) kept[(r * KS + 1) * NTB + threadIdx.x] = keep[1];
             }
@@ -610,8 +640,8 @@ __global__ __launch_bounds__(NTB, (R <= BATCHED_THREE_PER_CU_MAX_R) ? 3 : 2) voi
                     const double chi = kept[(r * KS + 0) * NTB + threadIdx.x];
                     if ((chi <= thr) && (all || chi < mean))
                         stage2_kept<PINHOLE, KS == 2>(T, cam, muv[(r * 2 + 0) * NTB + threadIdx.x],
-                                             muv[(r * 2 + 1) * NTB + threadIdx.x], rx[r], ry[r], rz[r], chi,
-                                             KS == 2 ? kept[(r * KS + 1) * NTB + threadIdx.x] : 0.0, s);
+                                                      muv[(r * 2 + 1) * NTB + threadIdx.x], rx[r], ry[r], rz[r], chi,
+                                                      KS == 2 ? kept[(r * KS + 1) * NTB + threadIdx.x] : 0.0, true, s);
                 }
             double vals[S2_USED];
             pack_sets(s, vals);
