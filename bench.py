@@ -183,39 +183,53 @@ def result_pose(res):
 # ---- sharded runs: choice of the exchange ------------------------------------------------------------
 def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
     """Sets up the exchange between the ranks and returns (mode, description).  Every decision is taken
-    collectively (all ranks end on the same path), and the in-kernel exchange is only used after one
-    trial loop through it has given the same result as the same loop through the stage launches."""
+    collectively (all ranks end on the same path).  The reference is the stage-launch loop with
+    torch.distributed's own all-reduce between the stages, which needs nothing from this library beyond
+    its kernels.  The in-kernel exchange (all of its waits are bounded, so a failure ends in an error, not
+    in a hang) is tried first and used only after one trial loop through it has given the reference's
+    result; failing that, the library's own RCCL communicator is tried the same way."""
     S = pkg.sharded
     want = os.environ.get("PICP_BENCH_EXCHANGE", "auto")   # auto | peer | rccl | torch
-    mode, how = "torch", f"{backend} through torch.distributed, stage launches"
-    if want in ("auto", "rccl") and backend == "nccl" and S.init_native_exchange(ctx):
-        # one all-reduce of known values through the library's communicator, checked on every rank
-        probe = ctx.to_device(np.full(4, float(dist.get_rank() + 1)))
-        ok = ctx.lib.picp_comm_allreduce(ctx.handle, ctx.ptr(probe), 4) == 0
-        ctx.synchronize()
-        ok = ok and bool(np.all(probe.cpu().numpy() == world * (world + 1) / 2))
-        if S._agree(ok):
-            mode, how = "rccl", "rccl all-reduces enqueued by the library on the kernels' stream, stage launches"
-        else:
-            S.shutdown_native_exchange(ctx)
+    rank = dist.get_rank()
+    ref = step_stages("torch")
+
+    def same(got):
+        return (got.num_iterations == ref.num_iterations and got.best_index == ref.best_index and
+                np.max(np.abs(result_pose(got) - result_pose(ref))) <= 1e-9)
+
+    notes = []
     if want in ("auto", "peer") and S.init_peer_exchange(ctx):
         ok, why = True, ""
         try:
-            ref = step_stages(mode)
-            got = step_peer()
-            same = (got.num_iterations == ref.num_iterations and got.best_index == ref.best_index and
-                    np.max(np.abs(result_pose(got) - result_pose(ref))) <= 1e-9)
-            if not same:
+            if not same(step_peer()):
                 ok, why = False, "its trial loop disagreed with the stage launches"
         except pkg._lib.PicpError as e:
             ok, why = False, f"its trial loop failed ({e})"
         if S._agree(ok):
             return "peer", "in-kernel exchange through peer memory (HIP IPC, xGMI stores), one launch per loop"
         if why:
-            print(f"rank {dist.get_rank()}: in-kernel exchange not used: {why}", file=sys.stderr)
+            print(f"rank {rank}: in-kernel exchange not used: {why}", file=sys.stderr)
         S.shutdown_peer_exchange(ctx)
-        how += " (the in-kernel exchange was set up but failed its trial)"
-    return mode, how
+        notes.append("the in-kernel exchange was set up but failed its trial")
+    if want in ("auto", "rccl") and backend == "nccl" and S.init_native_exchange(ctx):
+        # one all-reduce of known values through the library's communicator, then a trial loop
+        probe = ctx.to_device(np.full(4, float(rank + 1)))
+        ok = ctx.lib.picp_comm_allreduce(ctx.handle, ctx.ptr(probe), 4) == 0
+        ctx.synchronize()
+        ok = ok and bool(np.all(probe.cpu().numpy() == world * (world + 1) / 2))
+        if S._agree(ok):
+            try:
+                ok = same(step_stages("rccl"))
+            except pkg._lib.PicpError as e:
+                print(f"rank {rank}: library all-reduce not used: {e}", file=sys.stderr)
+                ok = False
+            ok = S._agree(ok)
+        if ok:
+            return "rccl", "; ".join(["rccl all-reduces enqueued by the library on the kernels' stream, two launches per "
+                                      "iteration"] + notes)
+        S.shutdown_native_exchange(ctx)
+        notes.append("the library's own RCCL communicator failed its trial")
+    return "torch", "; ".join([f"{backend} all-reduces through torch.distributed between stage launches"] + notes)
 
 
 def bench_loop(args):

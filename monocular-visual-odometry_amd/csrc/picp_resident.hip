@@ -345,8 +345,11 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     __shared__ unsigned long long wave_stamp[7][NTR / 64]; // the same boundaries as every wave of workgroup 0 sees them
 #define PICP_STAMP(k)                                                             \
     {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
         stamp[k] = __builtin_amdgcn_s_memrealtime();                              \
         if ((threadIdx.x & 63) == 0) wave_stamp[k][threadIdx.x >> 6] = stamp[k];  \
+        __builtin_amdgcn_sched_barrier(0);                                        \
     }
 #else
 #define PICP_STAMP(k)

@@ -262,6 +262,39 @@ def test_ranks_exchange_inside_the_single_launch_loop(world):
     assert seen_zero > 0 and seen_redo > 0
 
 
+@pytest.mark.parametrize("check_every", [1, 3, 64])
+def test_whole_rounds_on_degenerate_problems(check_every):
+    """picp_sharded_rounds (each scan folds its own records, the solve step runs in the next stage 1) on
+    one shard: tiny and empty inputs, zero-inlier iterations, the fallback to the stage-1 set, early
+    stops, and calls that end after every round or span the whole loop -- against the oracle."""
+    ctx = pkg.get_context(0)
+    cam = L.camera_struct([[180, 0, 320], [0, 180, 240], [0, 0, 1]], 640, 480)
+    for k, (M, n_it, v0, over) in enumerate(PEER_CASES + [(0, 4, [0] * 6, {})]):
+        if M > 100_000:
+            M = 50_001
+        uv, pw, _ = make_problem(M, seed=100 + k)
+        q = _peer_params(n_it, over)
+        sched = L.schedule_struct(n_it, q["min_inliers"], q["kernel_threshold"], q["min_kernel_threshold"],
+                                  q["max_kernel_threshold"], q["damping"], q["min_damping"], q["max_damping"])
+        stages = pkg.sharded.HipStages(ctx, ctx.soa(uv, pw), po.v2T(v0), cam, sched)
+        res, hist = pkg.sharded.run_sharded(stages, n_it, check_every=check_every)
+        params = po.IcpParams(num_iterations=n_it, min_inliers=q["min_inliers"], kernel_threshold=q["kernel_threshold"])
+        T_ref, valid_ref, h = po.projective_icp(uv, pw, po.v2T(v0), params, record_linear=True)
+        assert res.num_iterations == len(h["error"]) and bool(res.valid) == valid_ref, k
+        assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h["num_inliers"], dtype=np.int64)), k
+        assert np.array_equal(hist[:, L.H_N_INSIDE].astype(np.int64), np.array(h["n_inside"], dtype=np.int64)), k
+        assert np.array_equal(hist[:, L.H_KERNEL_THR], np.array(h["kernel_threshold"], dtype=np.float64)), k
+        assert np.array_equal(hist[:, L.H_DAMPING], np.array(h["dumping_factor"], dtype=np.float64)), k
+        if len(h["T"]):
+            assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), np.array(h["T"])) < 1e-9, k
+        if valid_ref:
+            kb = int(res.best_index)
+            assert abs(h["error"][kb] - min(h["error"])) <= 1e-9 * abs(min(h["error"])), k
+            assert rel_err(np.array(list(res.T)).reshape(4, 4), np.array(h["T"])[kb]) < 1e-9, k
+        else:
+            assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < 1e-9, k
+
+
 def _device_problem(ctx, M, seed=0, chunk=1 << 23):
     """The synthetic problem of tests/synthetic.make_problem generated on the device (torch), in
     chunks, as five SoA planes; returns (planes [5][M], true pose)."""
