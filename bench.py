@@ -54,8 +54,8 @@ REFERENCE_LOOP_RATE = 1.8e3    # correspondence-iterations/s of the reference's 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=["loop", "batched", "assoc"], default="loop")
     ap.add_argument("--corr", type=int, default=0, help="total correspondences (default 2^20 at 1 GPU, 2^26 sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
