@@ -36,7 +36,7 @@ struct picp_ctx {
     double* pinned; // host-pinned staging for small read-backs
     double* noalloc; // this device's address of the static workspace of picp_linearize_noalloc
     // register-resident loop (picp_resident.hip)
-    double* rslots;                // [3][num_cus][PICP_S2_DOUBLES] exchange records
+    double* rslots;                // [resident_slot_rows][PICP_S2_DOUBLES] exchange records: 3 slots of a launch's grid
     int64_t resident_limit;        // largest M the resident loop is used for (0: never)
     unsigned resident_spin_limit;  // polls before a waiting workgroup abandons the launch
     int resident_aborts;           // launches abandoned so far (each was repeated with the streaming kernels)
@@ -87,6 +87,7 @@ int sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const double
 
 // picp_resident.hip
 int64_t resident_capacity(const picp_ctx* ctx);
+int resident_slot_rows(const picp_ctx* ctx); // records to allocate for the in-kernel exchange (rslots)
 void resident_refill(picp_ctx* ctx);
 int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,

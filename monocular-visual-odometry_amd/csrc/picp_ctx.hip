@@ -70,7 +70,7 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     if (e == hipSuccess) e = hipMemset(ctx->scratch, 0, sizeof(double) * SCR_DOUBLES);
     if (e == hipSuccess) e = hipMalloc(&ctx->arrive, sizeof(unsigned) * 64);
     if (e == hipSuccess) e = hipMemset(ctx->arrive, 0, sizeof(unsigned) * 64);
-    if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * 3 * PICP_S2_DOUBLES * ctx->num_cus);
+    if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * PICP_S2_DOUBLES * resident_slot_rows(ctx));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->loop_done, hipEventDisableTiming);
     for (int k = 0; k < PICP_ASYNC_SLOTS && e == hipSuccess; ++k)
         e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);

@@ -80,6 +80,160 @@ __global__ void resident_fill_kernel(double* slots, int n) {
     if (i < n) slots[i] = __longlong_as_double((long long)SENTINEL_BITS);
 }
 
+// ---- 16-byte accesses for the wide (stage-2) records ------------------------------------------------
+// A record of the second exchange is 32 doubles, and every workgroup reads every record: with 8-byte
+// device-scope accesses that is 32 fabric writes per workgroup and 8 192 separate 8-byte loads per
+// workgroup and exchange, and the exchange took 0.8 us longer than the 4-double one at equal skew.
+// 16-byte accesses halve both counts.  HIP's atomics stop at 8 bytes, so these are written as the
+// instructions themselves (global_load/store_dwordx4 with the sc1 bit, i.e. device scope, as the
+// 8-byte atomics compile to); the loads of one thread are issued together and waited for inside the
+// same statement, so the compiler never sees a register whose load is still in flight.  Each 8-byte
+// half is checked for the sentinel on its own (a 16-byte store may become visible in two halves).
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void store_pair_sc1(double* p, f64x2 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// Eight consecutive records' pieces: one address, the record stride (RW doubles = 256 bytes) as the
+// instructions' immediate offsets.
+__device__ __forceinline__ void load8_pairs_sc1(const double* p, f64x2 (&v)[8]) {
+    static_assert(RW * sizeof(double) == 256, "the offsets below are the record stride");
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\t"
+        "global_load_dwordx4 %1, %8, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %2, %8, off offset:512 sc1\n\t"
+        "global_load_dwordx4 %3, %8, off offset:768 sc1\n\t"
+        "global_load_dwordx4 %4, %8, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %5, %8, off offset:1280 sc1\n\t"
+        "global_load_dwordx4 %6, %8, off offset:1536 sc1\n\t"
+        "global_load_dwordx4 %7, %8, off offset:1792 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p)
+        : "memory");
+}
+
+// grid_total for the 32-double records, in 16-byte pieces.  Thread (grp, pair) owns the column pair
+// (2 pair, 2 pair + 1) of the eight rows 8 grp .. 8 grp + 7: 32 groups cover 256 rows.  Rows past the
+// grid are read all the same (the slots are allocated for 256 rows and eight more) and dropped.
+// Fixed order of additions: a thread's rows in order, then the four groups of a wave (lane swaps),
+// then the waves in order.
+template <int NV>
+__device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const GridExchange& gx, unsigned& epoch,
+                                                 double* lds, int* lds_flag) {
+    constexpr int PW = RW / 2;      // 16 pairs per record
+    constexpr int GR = NTR / PW;    // 32 row groups
+    constexpr int B = MAX_GRID / GR; // 8 rows per thread
+    static_assert(B == 8 && NV <= RW, "load8_pairs_sc1 issues eight loads");
+    const int G = gridDim.x;
+#if defined(PICP_STAMPS) && PICP_STAMPS > 1
+    const unsigned long long xt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* cur = gx.slots + (size_t)(epoch % SLOTS) * G * RW;
+    double* old = gx.slots + (size_t)((epoch + SLOTS - 1u) % SLOTS) * G * RW; // the previous exchange's slot
+    ++epoch;
+    const f64x2 sentinel = {__longlong_as_double((long long)SENTINEL_BITS), __longlong_as_double((long long)SENTINEL_BITS)};
+    if (threadIdx.x < 64) {
+        // lane t < 16 publishes columns 2t and 2t + 1, which lanes 2t and 2t + 1 hold
+        const double v = (threadIdx.x < NV) ? mine : 0.0;
+        f64x2 rec;
+        rec.x = __shfl(v, (2 * lane) & 63, 64);
+        rec.y = __shfl(v, (2 * lane + 1) & 63, 64);
+        if (lane < PW) {
+            // The reset this wave stored at the end of the previous exchange has been acknowledged
+            // (the stores are write-through at device scope), so it is visible before this record is.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            store_pair_sc1(cur + (size_t)blockIdx.x * RW + 2 * lane, rec);
+        }
+    }
+
+#if defined(PICP_STAMPS) && PICP_STAMPS > 1
+    const unsigned long long xt1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int pair = threadIdx.x % PW, grp = threadIdx.x / PW;
+    __builtin_amdgcn_s_sleep(FIRST_LOOK_DELAY); // see grid_total
+
+#if defined(PICP_STAMPS) && PICP_STAMPS > 1
+    const unsigned long long xt2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const double* base = cur + (size_t)(grp * B) * RW + 2 * pair;
+    f64x2 v[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) v[k] = f64x2{0.0, 0.0};
+    if (grp * B < G) { // whole waves skip this on small grids
+        load8_pairs_sc1(base, v);
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            if (grp * B + k >= G) v[k] = f64x2{0.0, 0.0};
+    }
+
+#if defined(PICP_STAMPS) && PICP_STAMPS > 1
+    const unsigned long long xt3 = __builtin_amdgcn_s_memrealtime();
+#endif
+    unsigned spins = 0;
+    for (;;) {
+        bool missing = false;
+#pragma unroll
+        for (int k = 0; k < B; ++k) missing |= is_sentinel(v[k].x) || is_sentinel(v[k].y);
+        if (!missing) break;
+        if (++spins > gx.spin_limit) {
+            *lds_flag = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            if (is_sentinel(v[k].x)) v[k].x = __hip_atomic_load(base + k * RW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (is_sentinel(v[k].y)) v[k].y = __hip_atomic_load(base + k * RW + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+#if defined(PICP_STAMPS) && PICP_STAMPS > 1
+    const unsigned long long xt4 = __builtin_amdgcn_s_memrealtime();
+#endif
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        ax += v[k].x;
+        ay += v[k].y;
+    }
+    // the four row groups of a wave sit 16 lanes apart
+    ax = halve_bit4(ax, ax);
+    ay = halve_bit4(ay, ay);
+    ax = halve_bit5(ax, ax);
+    ay = halve_bit5(ay, ay);
+    if (lane < PW) {
+        lds[wave * RW + 2 * lane] = ax;
+        lds[wave * RW + 2 * lane + 1] = ay;
+    }
+
+#if defined(PICP_STAMPS) && PICP_STAMPS > 1
+    const unsigned long long xt5 = __builtin_amdgcn_s_memrealtime();
+#endif
+    __syncthreads();
+#if defined(PICP_STAMPS) && PICP_STAMPS > 1
+    const unsigned long long xt6 = __builtin_amdgcn_s_memrealtime();
+#endif
+    double tot = 0.0;
+    if (threadIdx.x < NV) {
+#pragma unroll
+        for (int w = 0; w < NTR / 64; ++w) tot += lds[w * RW + threadIdx.x];
+    }
+    out = tot;
+    // Every workgroup has published into `cur`, hence has finished reading `old`: reset this
+    // workgroup's record there; that slot is next used two exchanges from now.
+    if (threadIdx.x < PW) store_pair_sc1(old + (size_t)blockIdx.x * RW + 2 * threadIdx.x, sentinel);
+#if defined(PICP_STAMPS) && PICP_STAMPS > 1
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && epoch == 14)
+        printf("exchange 2, wg %d: published %.2f, slept %.2f, first look back %.2f (spins %u), all present %.2f, folded in wave %.2f, barrier %.2f, end %.2f us\n",
+               (int)blockIdx.x, (xt1 - xt0) * 0.01, (xt2 - xt0) * 0.01, (xt3 - xt0) * 0.01, spins, (xt4 - xt0) * 0.01, (xt5 - xt0) * 0.01,
+               (xt6 - xt0) * 0.01, (__builtin_amdgcn_s_memrealtime() - xt0) * 0.01);
+#endif
+    return *lds_flag == 0;
+}
+
 // Grid-wide sum of NV values.  `mine`: this workgroup's total of value tid (threads tid < NV).
 // On success every thread with tid < NV of EVERY workgroup holds the same grid total in `out`.
 // Returns false (uniformly over the workgroup) when a wait ran into its bound.
@@ -94,6 +248,7 @@ __device__ __forceinline__ bool grid_total(double mine, double& out, const GridE
     using Fold = PartialFold<NV, NTR, B>;
     constexpr int CW = Fold::CW, GR = Fold::G;
     static_assert(CW <= RW && RW <= 64, "the record is written by the first wave");
+    if constexpr (CW == RW) return grid_total_pairs<NV>(mine, out, gx, epoch, lds, lds_flag); // the 32-double records
     static_assert(B * GR >= MAX_GRID, "one load per row in flight");
     double* cur = gx.slots + (size_t)(epoch % SLOTS) * G * RW;
     double* old = gx.slots + (size_t)((epoch + SLOTS - 1u) % SLOTS) * G * RW; // the previous exchange's slot
@@ -342,6 +497,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     // left in the unused tail of the history row (entries 74 .. 79, microseconds since the iteration
     // began: stage 1, its workgroup sum, its exchange, stage 2, its workgroup sum, its exchange).
     unsigned long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long kept_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // iteration 6's, printed by every workgroup at the end
     __shared__ unsigned long long wave_stamp[7][NTR / 64]; // the same boundaries as every wave of workgroup 0 sees them
 #define PICP_STAMP(k)                                                             \
     {                                                                             \
@@ -425,18 +581,19 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         const bool advanced = solve_step(st, s1, s2, sc, record ? row : nullptr, &sh);
 #ifdef PICP_STAMPS
         if (record && threadIdx.x < 6) row[74 + threadIdx.x] = (double)(stamp[threadIdx.x + 1] - stamp[0]) * 0.01;
-        if (blockIdx.x == 0 && threadIdx.x == 0 && it == 6) {
-            for (int k = 1; k < 7; ++k) {
-                printf("boundary %d by wave:", k);
-                for (int w = 0; w < NTR / 64; ++w) printf(" %.2f", (double)(wave_stamp[k][w] - wave_stamp[0][0]) * 0.01);
-                printf("\n");
-            }
-        }
+        if (it == 6)
+            for (int k = 0; k < 7; ++k) kept_stamp[k] = stamp[k];
+        if (it == 7) kept_stamp[7] = stamp[0]; // = end of iteration 6's solve step
         __syncthreads();
 #endif
         if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
             hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
     }
+#ifdef PICP_STAMPS
+    if (threadIdx.x == 0 && host_state != nullptr && hist != nullptr) // (one line per workgroup, on the recorded runs only)
+        printf("wg %d: %llu %llu %llu %llu %llu %llu %llu %llu\n", (int)blockIdx.x, kept_stamp[0], kept_stamp[1],
+               kept_stamp[2], kept_stamp[3], kept_stamp[4], kept_stamp[5], kept_stamp[6], kept_stamp[7]);
+#endif
     if (blockIdx.x == 0 && threadIdx.x < PICP_STATE_DOUBLES) {
         state[threadIdx.x] = st[threadIdx.x];
         // a second copy straight into host-visible memory spares the caller a device-to-host copy
@@ -687,6 +844,10 @@ static int resident_grid(const picp_ctx* ctx) {
     const int g = ctx->num_cus < MAX_GRID ? ctx->num_cus : MAX_GRID;
     return (ctx->grid_limit > 0 && ctx->grid_limit < g) ? ctx->grid_limit : g;
 }
+
+// Three slots of up to MAX_GRID records, read in blocks of eight records that may reach past a
+// slot's last record (grid_total_pairs).
+int resident_slot_rows(const picp_ctx*) { return SLOTS * MAX_GRID + 8; }
 
 int64_t resident_capacity(const picp_ctx* ctx) {
     const int64_t cap = (int64_t)resident_grid(ctx) * NTR * R_MAX;
