@@ -136,6 +136,14 @@ int64_t picp_resident_capacity(picp_ctx* ctx);
  * the device is shared and part of the grid is not scheduled, the launch gives up and picp_run
  * repeats the loop with the streaming kernels; this returns how often that has happened on ctx. */
 int picp_resident_aborts(picp_ctx* ctx);
+/* The on-chip single launch has a lean form of stage 2 that is valid while every value it handles
+ * (points, measurements, camera matrix, the poses of the loop) is finite and below 2^199 in magnitude;
+ * it checks that itself, and a launch that meets anything else leaves at once and is run again in the
+ * form that assumes nothing, as are the next PICP_FULL_FORM_CALLS on-chip loops of ctx (the two forms
+ * add the same numbers in the same order: identical results; no counterpart in the reference).  This
+ * returns how often that has happened on ctx. */
+#define PICP_FULL_FORM_CALLS 8
+int picp_immoderate_exits(picp_ctx* ctx);
 /* Timing aid for benchmarks: runs the single-launch loop `reps` times from w_T_c0_host, each launch
  * bracketed by HIP events bound to that dispatch, and reports the mean and minimum kernel duration
  * in milliseconds.  Beyond picp_resident_capacity it times the single launch that streams the arrays

@@ -35,6 +35,7 @@ PICP_OK = 0
 PICP_ERR_CAPACITY = -3
 PICP_ERR_COMM = -5
 PICP_ERR_RETRY = -6
+FULL_FORM_CALLS = 8    # PICP_FULL_FORM_CALLS
 ASYNC_SLOTS = 4
 COMM_ID_BYTES = 128
 PEER_MAX_RANKS = 8
@@ -86,6 +87,7 @@ _SIGNATURES = {
     "picp_set_resident_limit": (C.c_int, [_P, C.c_int64]),
     "picp_resident_capacity": (C.c_int64, [_P]),
     "picp_resident_aborts": (C.c_int, [_P]),
+    "picp_immoderate_exits": (C.c_int, [_P]),
     "picp_profile_run": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
                                    C.POINTER(ScheduleStruct), _P, C.c_int32, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
@@ -282,6 +284,11 @@ class Context:
     def resident_aborts(self):
         """Single-launch loops that gave up at a grid-wide wait and were repeated with the streaming kernels."""
         return int(self.lib.picp_resident_aborts(self.handle))
+
+    def immoderate_exits(self):
+        """On-chip loops that met a value that is not finite and of moderate magnitude and were run again in the
+        form of the kernel that assumes nothing about magnitudes."""
+        return int(self.lib.picp_immoderate_exits(self.handle))
 
     def run(self, corr, w_T_c0, cam: CameraStruct, sched: ScheduleStruct, want_history=True):
         """picp_run on device arrays corr = [u, v, x, y, z].  Returns (ResultStruct, history ndarray)."""

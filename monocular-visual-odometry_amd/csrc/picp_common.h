@@ -48,6 +48,8 @@ struct picp_ctx {
     hipEvent_t loop_done;          // recorded behind a single-launch loop; the host waits for it, not for the stream
     hipEvent_t slot_done[PICP_ASYNC_SLOTS]; // the same for loops enqueued with picp_run_enqueue, one per slot
     int grid_limit;                // cap on the workgroups of the single-launch loops (0: one per CU)
+    int full_select_calls;         // on-chip loops that still use the form without assumptions on magnitudes
+    int immoderate_exits;          // on-chip loops that left because a value was not of moderate magnitude
     // sharded runs (picp_comm.hip)
     void* comm;                    // RCCL communicator of this rank, or null
     int comm_rank, comm_world;
@@ -75,6 +77,10 @@ enum : int {
     SCR_DOUBLES = 512,
 };
 enum : int { PINNED_DOUBLES = 4096, PINNED_SLOT0 = 2048, PINNED_SLOT_STRIDE = 128 }; // final states of enqueued loops
+
+// Value of the host-visible stop flag after an on-chip loop in its lean form met a value that is not
+// finite and of moderate magnitude: nothing was computed, the loop runs again in its other form.
+constexpr double STOP_IMMODERATE = 2.0;
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);

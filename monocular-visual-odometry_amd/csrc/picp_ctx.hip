@@ -149,6 +149,7 @@ int picp_set_stage2_order(picp_ctx* ctx, int32_t order) {
 int64_t picp_resident_capacity(picp_ctx* ctx) { return ctx ? resident_capacity(ctx) : 0; }
 
 int picp_resident_aborts(picp_ctx* ctx) { return ctx ? ctx->resident_aborts : 0; }
+int picp_immoderate_exits(picp_ctx* ctx) { return ctx ? ctx->immoderate_exits : 0; }
 
 int picp_synchronize(picp_ctx* ctx) {
     PICP_REQUIRE(ctx != nullptr, "picp_synchronize: null ctx");

@@ -745,6 +745,14 @@ int picp_finish(picp_ctx* ctx, const double* state, const double* hist, int32_t 
     return PICP_OK;
 }
 
+// After an on-chip loop in its lean form left because of an immoderate value: the next
+// PICP_FULL_FORM_CALLS on-chip loops of this context use the other form (such inputs come in runs,
+// and a lean launch that leaves costs a few microseconds).
+static void immoderate_exit(picp_ctx* ctx) {
+    ctx->immoderate_exits += 1;
+    ctx->full_select_calls = PICP_FULL_FORM_CALLS;
+}
+
 int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y, const double* z,
              int64_t M, const double* w_T_c0_host, const picp_camera* cam, const picp_schedule* sched, double* state,
              double* hist, int32_t hist_rows, picp_result* result) {
@@ -775,6 +783,15 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
                                       ctx->pinned, nullptr, nullptr))
             return rc;
         if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
+        if (ctx->pinned[ST_STOP] == STOP_IMMODERATE) {
+            // The lean form met a value that is not finite and moderate and left before computing anything:
+            // run the form without that assumption, now and for the next calls (such inputs come in runs).
+            immoderate_exit(ctx);
+            if (int rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
+                                          ctx->pinned, nullptr, nullptr))
+                return rc;
+            if (int rc = wait_for_loop(ctx)) return rc;
+        }
         if (ctx->pinned[ST_STOP] != 0.0) {
             ctx->abort_streak = 0;
             result_from_state(ctx->pinned, w_T_c0_host, result);
@@ -917,6 +934,12 @@ int picp_run_collect(picp_ctx* ctx, int32_t slot, const double* w_T_c0_host, pic
     DeviceGuard g(ctx->device);
     PICP_HIP_CHECK(hipEventSynchronize(ctx->slot_done[slot]));
     const double* h = ctx->pinned + PINNED_SLOT0 + (size_t)slot * PINNED_SLOT_STRIDE;
+    if (h[ST_STOP] == STOP_IMMODERATE) { // nothing computed; the next launches use the form without assumptions
+        immoderate_exit(ctx);
+        set_error("picp_run_collect: the launch of slot %d met values that are not finite and of moderate magnitude and "
+                  "left; run it again (picp_run or picp_run_enqueue)", (int)slot);
+        return PICP_ERR_RETRY;
+    }
     if (h[ST_STOP] == 0.0) { // the launch was abandoned at a grid-wide wait
         ctx->resident_aborts += 1;
         set_error("picp_run_collect: the launch of slot %d gave up at an exchange (device shared with other work)", (int)slot);

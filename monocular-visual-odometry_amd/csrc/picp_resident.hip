@@ -375,6 +375,13 @@ __device__ __forceinline__ bool cross_total(double mine, double& out, const Peer
     return *lds_flag == 0;
 }
 
+// Finite and far from overflow in any product the stages form with it (see stage2_kept, MODERATE):
+// |v| < 2^199 (about 8e59), read off the exponent field, which is all ones for infinities and NaN.
+// Integer arithmetic on purpose: for the pose, which is the same in every lane, it runs on the scalar unit.
+__device__ __forceinline__ unsigned exponent_field(double v) { return ((unsigned)__double2hiint(v) >> 20) & 0x7ffu; }
+constexpr unsigned MODERATE_EXPONENT = 1023u + 199u;
+__device__ __forceinline__ bool moderate(double v) { return exponent_field(v) < MODERATE_EXPONENT; }
+
 // Stage 1 of one correspondence (as stage1_point) that also leaves what stage 2 needs of it in
 // `keep`: chi (NaN when the pair is outside the image or above the threshold, so that every later
 // comparison with it is false) and 1 / (K p)_z, the one division of the projection.
@@ -407,7 +414,13 @@ __device__ __forceinline__ void stage1_keep(const double* __restrict__ T, const 
 // the compiler interleaves their dependent chains; behind a branch per correspondence each chain ran
 // on its own, exposed to its full latency (measured: a wave alone on its SIMD needed 570 cycles per
 // correspondence for about 100 instructions).
-template <bool PINHOLE, bool HAVE_ZI = true>
+//
+// MODERATE: the caller has checked that the pose, the camera matrix and everything this lane loaded
+// (point and measurement, kept or not) are finite and of moderate magnitude (moderate() below).  Then
+// zeroing the reciprocal alone is enough: the camera point, K p and the residual of a lane outside
+// the set stay finite, every entry of its Jacobian carries the factor 1/z = 0 and is an exact zero, and
+// so is every product.  That spares ten of the twelve selects per correspondence.
+template <bool PINHOLE, bool HAVE_ZI = true, bool MODERATE = false>
 __device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const CameraK& cam, double mu, double mv,
                                             double x, double y, double z, double chi, double zi, bool keep,
                                             Stage2Sums& s) {
@@ -416,9 +429,11 @@ __device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const 
     p.pcx = __builtin_fma(T[2], z, __builtin_fma(T[1], y, T[0] * x)) + T[3];
     p.pcy = __builtin_fma(T[6], z, __builtin_fma(T[5], y, T[4] * x)) + T[7];
     p.pcz = __builtin_fma(T[10], z, __builtin_fma(T[9], y, T[8] * x)) + T[11];
-    p.pcx = keep ? p.pcx : 0.0;
-    p.pcy = keep ? p.pcy : 0.0;
-    p.pcz = keep ? p.pcz : 0.0;
+    if (!MODERATE) {
+        p.pcx = keep ? p.pcx : 0.0;
+        p.pcy = keep ? p.pcy : 0.0;
+        p.pcz = keep ? p.pcz : 0.0;
+    }
     if (PINHOLE) {
         p.h0 = __builtin_fma(cam.k[2], p.pcz, cam.k[0] * p.pcx);
         p.h1 = __builtin_fma(cam.k[5], p.pcz, cam.k[4] * p.pcy);
@@ -432,8 +447,10 @@ __device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const 
     zi = keep ? zi : 0.0;
     double e0 = mu - div_with_recip(p.h0, p.h2, zi);
     double e1 = mv - div_with_recip(p.h1, p.h2, zi);
-    e0 = keep ? e0 : 0.0;
-    e1 = keep ? e1 : 0.0;
+    if (!MODERATE) {
+        e0 = keep ? e0 : 0.0;
+        e1 = keep ? e1 : 0.0;
+    }
     p.zi = zi;
     double J0[6], J1[6];
     jacobian_rows<PINHOLE>(p, cam, J0, J1);
@@ -442,7 +459,12 @@ __device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const 
     s.n += keep ? 1u : 0u;
 }
 
-template <int R, bool PINHOLE>
+// MODERATE: the lean form of stage 2 (stage2_kept).  It needs every loaded value, the camera matrix
+// (checked by the host) and every pose of the loop to be moderate(): the lanes count what is not, the
+// count travels with the first exchange of every iteration, and when it is not zero every workgroup
+// leaves at the same point, workgroup 0 having set the host-visible stop flag to STOP_IMMODERATE; the
+// host then runs the kernel's other form, which makes no assumption.
+template <int R, bool PINHOLE, bool MODERATE>
 __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                           const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, int64_t M,
@@ -471,19 +493,23 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     const int64_t first = (int64_t)blockIdx.x * NTR + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * NTR;
     int mine = 0; // this thread holds correspondences r = 0 .. mine-1
+    bool tame = true; // everything this lane loaded is moderate()
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = first + r * step;
         const bool ok = i < M;
         const int64_t j = ok ? i : 0;
-        muv[(r * 2 + 0) * NTR + threadIdx.x] = u[j];
-        muv[(r * 2 + 1) * NTR + threadIdx.x] = v[j];
+        const double mu = u[j], mv = v[j];
+        muv[(r * 2 + 0) * NTR + threadIdx.x] = mu;
+        muv[(r * 2 + 1) * NTR + threadIdx.x] = mv;
         rx[r] = x[j];
         ry[r] = y[j];
         rz[r] = z[j];
         homogeneous_nan(rx[r], ry[r], rz[r]);
+        if (MODERATE) tame = tame && moderate(mu) && moderate(mv) && moderate(rx[r]) && moderate(ry[r]) && moderate(rz[r]);
         mine += ok ? 1 : 0;
     }
+
     // loop entry (src/ProjectiveICP.py:157-171): every workgroup builds its own copy of the state
     if (threadIdx.x == 0) {
         init_state(st, pose0.m, sc.kernel_threshold, sc.damping, sc.num_iterations);
@@ -533,35 +559,55 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
             }
         PICP_STAMP(1);
         {
-            const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
-            const double tot = block_sum<3, NTR, false>(vals, lds);
+            constexpr int NV1 = MODERATE ? 4 : 3; // the lean form also counts the lanes with immoderate values
+            static_assert(NV1 <= PICP_S1_DOUBLES, "stage-1 record");
+            double tot;
+            if constexpr (MODERATE) {
+                // the pose is the same in every workgroup; testing it here, without branches and beside
+                // stage 1's arithmetic, keeps it off the path from the solve step to stage 1
+                unsigned pose_exponent = 0;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) pose_exponent = max(pose_exponent, exponent_field(T[i]));
+                const bool pose_tame = pose_exponent < MODERATE_EXPONENT;
+                const double vals[4] = {a.sum_chi, (double)a.n1, (double)a.n_inside, (tame && pose_tame) ? 0.0 : 1.0};
+                tot = block_sum<4, NTR, false>(vals, lds);
+            } else {
+                const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
+                tot = block_sum<3, NTR, false>(vals, lds);
+            }
             PICP_STAMP(2);
             double g = tot;
-            if (gridDim.x > 1 && !grid_total<3, 2>(tot, g, gx, epoch, lds_fold, &flag)) return;
-            if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < 3) ? g : 0.0;
+            if (gridDim.x > 1 && !grid_total<NV1, 2>(tot, g, gx, epoch, lds_fold, &flag)) return;
+            if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < NV1) ? g : 0.0;
             __syncthreads();
         }
         PICP_STAMP(3);
+        if (MODERATE && s1[S1_PAD] != 0.0) { // identical in every workgroup
+            if (blockIdx.x == 0 && threadIdx.x == 0 && host_state != nullptr) host_state[ST_STOP] = STOP_IMMODERATE;
+            return;
+        }
         const double n1 = s1[S1_COUNT]; // identical in every workgroup, so the branch below is grid-uniform
         if (n1 != 0.0) {
             const double mean = uniform(s1[S1_SUM_CHI] / n1); // np.mean, src/ProjectiveICP.py:301
             Stage2Sums s;
             s.clear();
+            if (KEEP) {
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (KEEP || r < mine) {
-                        if (KEEP) {
-                        const double chi = kept[(r * 2 + 0) * NTR + threadIdx.x];
-                        // NaN (rejected by stage 1) fails both tests; `all`: the stage-1 set, else chi < mean (:302)
-                        const bool in_set = (r < mine) && (chi <= thr) && (all || chi < mean);
-                        stage2_kept<PINHOLE>(T, cam, muv[(r * 2 + 0) * NTR + threadIdx.x],
-                                             muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], chi,
-                                             kept[(r * 2 + 1) * NTR + threadIdx.x], in_set, s);
-                    } else {
+                for (int r = 0; r < R; ++r) {
+                    const double chi = kept[(r * 2 + 0) * NTR + threadIdx.x];
+                    // NaN (rejected by stage 1) fails both tests; `all`: the stage-1 set, else chi < mean (:302)
+                    const bool in_set = (r < mine) && (chi <= thr) && (all || chi < mean);
+                    stage2_kept<PINHOLE, true, MODERATE>(T, cam, muv[(r * 2 + 0) * NTR + threadIdx.x],
+                                                         muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], chi,
+                                                         kept[(r * 2 + 1) * NTR + threadIdx.x], in_set, s);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r < mine)
                         stage2_point<PINHOLE>(T, cam, thr, mean, all, muv[(r * 2 + 0) * NTR + threadIdx.x],
                                               muv[(r * 2 + 1) * NTR + threadIdx.x], rx[r], ry[r], rz[r], s);
-                    }
-                }
+            }
             PICP_STAMP(4);
             double vals[S2_USED];
             pack_sets(s, vals);
@@ -861,11 +907,17 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
                             hipEvent_t e1) {
     const CameraK c = camera_of(cam);
     GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
-    auto kern = is_pinhole(cam->K) ? icp_resident_kernel<R, true> : icp_resident_kernel<R, false>;
+    // The lean form where it exists (it differs only where stage 1's results are kept on chip), unless
+    // a recent loop met immoderate values or the camera matrix itself is not moderate.
+    bool lean = (R <= R_KEEP_MAX) && ctx->full_select_calls == 0;
+    for (int i = 0; i < 9; ++i) lean = lean && fabs(cam->K[i]) < 0x1p199; // moderate(), as the kernel tests its values
+    if ((R <= R_KEEP_MAX) && ctx->full_select_calls > 0) ctx->full_select_calls -= 1;
+    auto kern = is_pinhole(cam->K) ? (lean ? icp_resident_kernel<R, true, (R <= R_KEEP_MAX)> : icp_resident_kernel<R, true, false>)
+                                   : (lean ? icp_resident_kernel<R, false, (R <= R_KEEP_MAX)> : icp_resident_kernel<R, false, false>);
     constexpr unsigned kept_bytes = R * (R <= R_KEEP_MAX ? 4 : 2) * NTR * sizeof(double); // u, v (, chi, 1/z)
     if (kept_bytes > 48 * 1024) { // above the default dynamic-LDS allowance: raise it once per kernel and device
-        static bool raised[2][MAX_DEVICES] = {};
-        const int which = is_pinhole(cam->K) ? 1 : 0;
+        static bool raised[4][MAX_DEVICES] = {};
+        const int which = (is_pinhole(cam->K) ? 1 : 0) + (lean ? 2 : 0);
         if (ctx->device >= MAX_DEVICES || !raised[which][ctx->device]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)kept_bytes);

@@ -512,6 +512,53 @@ def test_degenerate_points_on_every_path(ctx, loop_path):
     assert rel_err(np.array(list(res2.T)).reshape(4, 4), T2) < TOL
 
 
+def test_immoderate_values_leave_the_lean_form(ctx):
+    """The on-chip single launch runs a lean form of stage 2 while every value is finite and below 2^199, checks
+    that itself and otherwise leaves and is run again in the form that assumes nothing (as are the next
+    FULL_FORM_CALLS loops).  One huge point among regular ones: the oracle's counts and pose, one exit counted;
+    a regular problem gives bit-identical histories in the two forms; loops in flight recover the same way."""
+    ctx.set_resident_limit(None)
+    cam, sched = bundled_cam(), yaml_sched(6, disable_stop=True)
+    params = po.IcpParams(num_iterations=6, disable_stop=True)
+    uv, pw, _ = make_problem(3000, seed=77)
+    reg = ctx.soa(uv, pw)
+    for _ in range(L.FULL_FORM_CALLS + 1):                     # whatever earlier tests left: back to the lean form
+        res_lean, hist_lean = ctx.run(reg, np.eye(4), cam, sched)
+    exits = ctx.immoderate_exits()
+    res_lean, hist_lean = ctx.run(reg, np.eye(4), cam, sched)
+    assert ctx.immoderate_exits() == exits
+    for bad_value, column in ((1e300, 0), (np.inf, 2), (np.nan, 1)):
+        uv_b, pw_b = uv.copy(), pw.copy()
+        pw_b[1234, column] = bad_value
+        with np.errstate(all="ignore"):
+            T_ref, _, h = po.projective_icp(uv_b, pw_b, np.eye(4), params, record_linear=True)
+        res, hist = ctx.run(ctx.soa(uv_b, pw_b), np.eye(4), cam, sched)
+        exits += 1
+        assert ctx.immoderate_exits() == exits
+        assert np.array_equal(hist[:, L.H_N_INSIDE].astype(np.int64), np.array(h["n_inside"]))
+        assert np.array_equal(hist[:, L.H_NUM_INLIERS].astype(np.int64), np.array(h["num_inliers"]))
+        assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
+        # the next loops run in the other form: no further exit, and the same bits as the lean form gave
+        res_full, hist_full = ctx.run(reg, np.eye(4), cam, sched)
+        assert ctx.immoderate_exits() == exits
+        assert np.array_equal(hist_full, hist_lean)
+        assert np.array_equal(np.array(list(res_full.T)), np.array(list(res_lean.T)))
+        for _ in range(L.FULL_FORM_CALLS):
+            ctx.run(reg, np.eye(4), cam, sched)
+    # a measurement instead of a point, and a loop in flight (enqueue / collect)
+    uv_b = uv.copy()
+    uv_b[17, 1] = -1e250
+    with np.errstate(all="ignore"):
+        T_ref, _, h = po.projective_icp(uv_b, pw, np.eye(4), params)
+    plan = ctx.plan(ctx.soa(uv_b, pw), cam, sched, want_history=False)
+    plan.enqueue(np.eye(4), 0)
+    res = plan.collect(0)
+    assert ctx.immoderate_exits() == exits + 1
+    assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
+    for _ in range(L.FULL_FORM_CALLS + 1):
+        ctx.run(reg, np.eye(4), cam, sched)
+
+
 def test_loop_plan_equals_run(ctx):
     """Context.plan (arguments marshalled once) gives what Context.run gives, call after call, for
     different start poses over the same arrays."""
