@@ -348,8 +348,8 @@ __device__ __forceinline__ double wave_column_sums(double (&v)[N]) {
 }
 
 // Sums NV per-thread values over a workgroup of NT threads (NT a multiple of 64, <= 1024).
-// lds: at least (NT/64)*64 doubles.  On return every thread with tid < NV holds the workgroup
-// total of value tid (other threads: unspecified).  Fixed order of additions: wave_column_sums
+// lds: at least (NT/64)*64 doubles.  On return lane t < NV of EVERY wave holds the workgroup total
+// of value t (other lanes: unspecified).  Fixed order of additions: wave_column_sums
 // inside each wave, then waves 0,1,2,.. in order.
 // TRAILING_SYNC = false leaves out the final barrier: the caller must not write `lds` again before
 // its next workgroup barrier.
@@ -370,9 +370,9 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
         else if ((lane & 1) == 0)
             lds[wave * 64 + (lane >> 1)] = tot; // with 32 values, lanes 2k and 2k+1 hold the total of value k
         __syncthreads();
-        if (threadIdx.x < NV) {
+        if (lane < NV) {
 #pragma unroll
-            for (int w = 0; w < NT / 64; ++w) out += lds[w * 64 + threadIdx.x];
+            for (int w = 0; w < NT / 64; ++w) out += lds[w * 64 + lane];
         }
     } else {
 #pragma unroll
@@ -381,9 +381,9 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
             if (lane == 0) lds[wave * 64 + i] = s;
         }
         __syncthreads();
-        if (threadIdx.x < NV) {
+        if (lane < NV) {
 #pragma unroll
-            for (int w = 0; w < NT / 64; ++w) out += lds[w * 64 + threadIdx.x];
+            for (int w = 0; w < NT / 64; ++w) out += lds[w * 64 + lane];
         }
     }
     if (TRAILING_SYNC) __syncthreads();
@@ -462,9 +462,9 @@ struct PartialFold {
         }
         __syncthreads();
         double out = 0.0;
-        if (threadIdx.x < NV) {
+        if (lane < NV) { // every wave: lane t ends with the total of column t
 #pragma unroll
-            for (int w = 0; w < NT / 64; ++w) out += lds[w * CW + threadIdx.x];
+            for (int w = 0; w < NT / 64; ++w) out += lds[w * CW + lane];
         }
         return out;
     }
@@ -654,16 +654,46 @@ __device__ inline double numpy_sum10(const double* a) {
 // lane), a third wave fills the history row's H and b, and after one barrier the lanes write the
 // state block and the history row in parallel.
 
-// Fills the H, b and padding entries of a history row from the stage records (lanes tid = 0..63).
-__device__ __forceinline__ void fill_history_linear(double* hist_row, const double* s1, const double* s2, int tid) {
-    const bool have = (s1[S1_N_INSIDE] != 0.0) && (s1[S1_COUNT] != 0.0);
+// A reduced stage record, read either from memory (LDS or global) or from the lanes of the calling
+// wave (lane t holds entry t; every lane of the wave must be active in dyn()).
+struct MemRecord {
+    const double* p;
+    template <int I>
+    __device__ __forceinline__ double at() const { return p[I]; }
+    __device__ __forceinline__ double dyn(int i) const { return p[i]; }
+};
+struct LaneRecord;
+
+// The entries of the stage records that the tail's scalar decisions need.
+struct StageScalars {
+    double n_inside, n1, sum_chi; // stage 1
+    double s2_n, s2_chi;          // stage 2: members and sum of chi of the summed set
+};
+template <class R1, class R2>
+__device__ __forceinline__ StageScalars stage_scalars(const R1& r1, const R2& r2) {
+    StageScalars q;
+    q.n_inside = r1.template at<S1_N_INSIDE>();
+    q.n1 = r1.template at<S1_COUNT>();
+    q.sum_chi = r1.template at<S1_SUM_CHI>();
+    q.s2_n = r2.template at<S2_N>();
+    q.s2_chi = r2.template at<S2_CHI>();
+    return q;
+}
+
+// Fills the H, b and padding entries of a history row from the stage records (a whole wave, lanes
+// tid = 0..63).
+template <class R2>
+__device__ __forceinline__ void fill_history_linear(double* hist_row, const StageScalars& q, const R2& r2, int tid) {
+    const bool have = (q.n_inside != 0.0) && (q.n1 != 0.0);
+    const int i = tid / 6, j = tid % 6;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int tri = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo); // index of (lo, hi) in the row-major upper triangle
+    const int idx = tid < 36 ? S2_H + tri : (tid < 42 ? S2_B + (tid - 36) : 0);
+    const double val = r2.dyn(idx); // every lane fetches: a lane-to-lane fetch needs the whole wave
     if (tid < 36) {
-        const int i = tid / 6, j = tid % 6;
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        const int tri = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo); // index of (lo, hi) in the row-major upper triangle
-        hist_row[PICP_H_H + tid] = have ? s2[S2_H + tri] : 0.0;
+        hist_row[PICP_H_H + tid] = have ? val : 0.0;
     } else if (tid < 42) {
-        hist_row[PICP_H_B + (tid - 36)] = have ? s2[S2_B + (tid - 36)] : 0.0;
+        hist_row[PICP_H_B + (tid - 36)] = have ? val : 0.0;
     } else if (tid < 42 + (PICP_HIST_STRIDE - (PICP_H_H + 36))) {
         hist_row[PICP_H_H + 36 + (tid - 42)] = 0.0;
     }
@@ -680,6 +710,7 @@ struct StepShared {
     int it;        // 1-based number of this iteration (:179)
     int ring_slot; // slot of the slope ring buffer that receives `slope`, or -1
     int improved;  // this iteration's error is the smallest so far (first minimum wins, :249)
+    double next[4]; // solve_step_lanes: what the next iteration's stages read besides Tinv (NEXT_*)
 #ifdef PICP_STAMPS
     unsigned long long t[6]; // diagnostic build: clock stamps inside solve_step
 #endif
@@ -702,6 +733,12 @@ template <int LANE>
 __device__ __forceinline__ float lane_bcastf(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), LANE));
 }
+struct LaneRecord {
+    double v;
+    template <int I>
+    __device__ __forceinline__ double at() const { return lane_bcast<I>(v); }
+    __device__ __forceinline__ double dyn(int i) const { return lane_gather(v, i); }
+};
 
 // Pose chain, one whole wave (all 64 lanes active): H and b of the chosen set, damped solve, v2T, pose
 // product, inverse (src/ProjectiveICP.py:269-271, :232).  On a single lane this is a chain of some
@@ -715,27 +752,28 @@ __device__ __forceinline__ float lane_bcastf(float v) {
 //   solution.  After step 5 column 6 holds dx.
 // The three float32 sine/cosine pairs of v2T are computed by three lanes at once; the rest (pose
 // product, cofactor inverse) has uniform operands and is computed by every lane alike, lane 0 stores it.
-__device__ __forceinline__ void step_pose_wave(const double* st, const double* s1, const double* s2, StepShared* sh) {
+template <class R2>
+__device__ __forceinline__ void step_pose_wave(const double* st, const StageScalars& q, const R2& r2, StepShared* sh) {
     const int lane = threadIdx.x & 63;
     double T1[16], dx[6];
-    if (s1[S1_N_INSIDE] == 0.0) { // uniform: __one_step returns before the solve when there are no points (:263)
+    if (q.n_inside == 0.0) { // uniform: __one_step returns before the solve when there are no points (:263)
 #pragma unroll
         for (int i = 0; i < 6; ++i) dx[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) T1[i] = st[ST_W_T_C + i];
     } else {
-        const bool have = (s1[S1_COUNT] != 0.0); // else H = 0, b = 0 (:300)
+        const bool have = (q.n1 != 0.0); // else H = 0, b = 0 (:300)
         const int i = lane >> 3, k = lane & 7;
+        const bool in_h = (i < 6 && k < 6), in_b = (i < 6 && k == 6);
+        const int lo = i < k ? i : k, hi = i < k ? k : i;
+        const int tri = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo); // index of (lo, hi) in the row-major upper triangle
+        const double entry = r2.dyn(in_h ? S2_H + tri : (in_b ? S2_B + i : 0)); // fetched by every lane of the wave
         double a = 0.0;
-        if (i < 6 && k < 7) {
-            if (k < 6) {
-                const int lo = i < k ? i : k, hi = i < k ? k : i;
-                const int tri = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo); // index of (lo, hi) in the row-major upper triangle
-                a = have ? s2[S2_H + tri] : 0.0;
-                if (i == k) a += st[ST_LAMBDA]; // :269
-            } else {
-                a = have ? -s2[S2_B + i] : -0.0; // :270
-            }
+        if (in_h) {
+            a = have ? entry : 0.0;
+            if (i == k) a += st[ST_LAMBDA]; // :269
+        } else if (in_b) {
+            a = have ? -entry : -0.0; // :270
         }
 #define PICP_GJ_STEP(J)                                                      \
     {                                                                        \
@@ -795,20 +833,20 @@ __device__ __forceinline__ void step_pose_wave(const double* st, const double* s
 }
 
 // Schedule chain, one lane: error and inlier count of the chosen set, then :200-228.
-__device__ inline void step_schedule_chain(const double* st, const double* s1, const double* s2,
-                                           const picp_schedule& sc, StepShared* sh, StepShared& out) {
-    const double n_inside = s1[S1_N_INSIDE];
-    const double n1 = s1[S1_COUNT];
+__device__ inline void step_schedule_chain(const double* st, const StageScalars& q, const picp_schedule& sc,
+                                           StepShared* sh, StepShared& out) {
+    const double n_inside = q.n_inside;
+    const double n1 = q.n1;
     const bool redo_mode = (st[ST_MODE] != 0.0);
     double error = d_inf(), n_inliers = 0.0, n_stage2 = 0.0, used_stage2 = 0.0, mean_stage1 = 0.0;
     const bool done = (n_inside != 0.0); // :263 vs :273
     if (done && n1 != 0.0) {
-        mean_stage1 = s1[S1_SUM_CHI] / n1;
+        mean_stage1 = q.sum_chi / n1;
         used_stage2 = redo_mode ? 0.0 : 1.0;
         // in redo mode the number of mean-filter survivors was kept in the state block
-        n_stage2 = redo_mode ? st[ST_N_STAGE2] : s2[S2_N];
-        n_inliers = s2[S2_N];
-        error = (n_inliers > 0.0) ? s2[S2_CHI] / n_inliers : d_inf(); // :319-321
+        n_stage2 = redo_mode ? st[ST_N_STAGE2] : q.s2_n;
+        n_inliers = q.s2_n;
+        error = (n_inliers > 0.0) ? q.s2_chi / n_inliers : d_inf(); // :319-321
     }
     // kernel threshold schedule (:200-205)
     double thr = st[ST_THR];
@@ -889,8 +927,10 @@ __device__ __forceinline__ bool solve_step(double* st, const double* s1, const d
                                            double* hist_row, StepShared* sh) {
     const int tid = threadIdx.x;
     const bool redo_mode = (st[ST_MODE] != 0.0);
-    const double n_set = s2[S2_N];
-    if (s1[S1_N_INSIDE] != 0.0 && s1[S1_COUNT] != 0.0 && !redo_mode && n_set < (double)sc.min_inliers) { // :307
+    const MemRecord r1{s1}, r2{s2};
+    const StageScalars q = stage_scalars(r1, r2);
+    const double n_set = q.s2_n;
+    if (q.n_inside != 0.0 && q.n1 != 0.0 && !redo_mode && n_set < (double)sc.min_inliers) { // :307
         __syncthreads(); // every thread has read the mode flag
         if (tid == 0) {
             st[ST_MODE] = 1.0;
@@ -902,16 +942,16 @@ __device__ __forceinline__ bool solve_step(double* st, const double* s1, const d
 #ifdef PICP_STAMPS
     if (tid == 0) sh->t[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (tid < 64) step_pose_wave(st, s1, s2, sh);
+    if (tid < 64) step_pose_wave(st, q, r2, sh);
 #ifdef PICP_STAMPS
     if (tid == 0) sh->t[1] = __builtin_amdgcn_s_memrealtime();
 #endif
     StepShared mine; // the schedule chain's results, in the registers of the lane that computed them
-    if (tid == 64) step_schedule_chain(st, s1, s2, sc, sh, mine);
+    if (tid == 64) step_schedule_chain(st, q, sc, sh, mine);
 #ifdef PICP_STAMPS
     if (tid == 64) sh->t[2] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (hist_row != nullptr && tid >= 128 && tid < 192) fill_history_linear(hist_row, s1, s2, tid - 128);
+    if (hist_row != nullptr && tid >= 128 && tid < 192) fill_history_linear(hist_row, q, r2, tid - 128);
     __syncthreads();
 #ifdef PICP_STAMPS
     if (tid == 0) sh->t[3] = __builtin_amdgcn_s_memrealtime();
@@ -944,7 +984,7 @@ __device__ __forceinline__ bool solve_step(double* st, const double* s1, const d
             st[ST_BEST_IT] = (double)(mine.it - 1);
         }
         if (hist_row != nullptr) {
-            const double n_in = s1[S1_N_INSIDE], n_s1 = s1[S1_COUNT];
+            const double n_in = q.n_inside, n_s1 = q.n1;
             hist_row[PICP_H_ERROR] = mine.error;
             hist_row[PICP_H_NUM_INLIERS] = mine.n_inliers;
             hist_row[PICP_H_KERNEL_THR] = mine.thr;
@@ -964,6 +1004,97 @@ __device__ __forceinline__ bool solve_step(double* st, const double* s1, const d
                (sh->t[4] - sh->t[0]) * 0.01, (sh->t[5] - sh->t[0]) * 0.01, (sh->t[1] - sh->t[0]) * 0.01, (sh->t[2] - sh->t[0]) * 0.01, (sh->t[3] - sh->t[0]) * 0.01,
                (__builtin_amdgcn_s_memrealtime() - sh->t[0]) * 0.01);
 #endif
+    return true;
+}
+
+// The tail for a loop that receives the reduced records in registers -- lane t of EVERY wave holds
+// entry t of the stage-1 record in g1 and of the stage-2 record in g2 -- and whose next iteration
+// reads its inputs from `sh` (camera pose sh->Tinv, and sh->next[NEXT_*]) instead of the state block.
+// That takes three workgroup barriers and two LDS round trips out of the path between one iteration's
+// last exchange and the next iteration's stage 1, compared with solve_step: no record is written to
+// LDS and waited for, and after the single barrier behind the two chains the stages may start while
+// the state block and the history row are still being brought up to date.  Those writes are ordered
+// before their next readers (the next tail, the caller's final copy of the state) by the barriers the
+// caller passes in between; the caller puts one barrier before it reads the state block or hist_row.
+// Same return value as solve_step.  sh->Tinv and sh->next must hold the loop-entry values before the
+// first iteration (init_next).  redo_mode: sh->next[NEXT_MODE] as the caller read it at the head of this
+// iteration (the schedule chain overwrites it before the barrier, so it is not read again here).
+enum : int { NEXT_THR = 0, NEXT_MODE = 1, NEXT_IT = 2, NEXT_STOP = 3 };
+
+__device__ inline void init_next(const double* st, StepShared* sh) {
+    for (int i = 0; i < 16; ++i) sh->Tinv[i] = st[ST_C_T_W + i];
+    sh->next[NEXT_THR] = st[ST_THR];
+    sh->next[NEXT_MODE] = 0.0;
+    sh->next[NEXT_IT] = st[ST_IT];
+    sh->next[NEXT_STOP] = st[ST_STOP];
+}
+
+__device__ __forceinline__ bool solve_step_lanes(double* st, double g1, double g2, bool redo_mode,
+                                                 const picp_schedule& sc, double* hist_row, StepShared* sh) {
+    const int tid = threadIdx.x;
+    const LaneRecord r1{g1}, r2{g2};
+    const StageScalars q = stage_scalars(r1, r2); // v_readlane: the same scalars in every wave
+    if (q.n_inside != 0.0 && q.n1 != 0.0 && !redo_mode && q.s2_n < (double)sc.min_inliers) { // :307
+        __syncthreads(); // every thread has read the mode flag
+        if (tid == 0) {
+            st[ST_MODE] = 1.0;
+            st[ST_N_STAGE2] = q.s2_n;
+            sh->next[NEXT_MODE] = 1.0;
+        }
+        __syncthreads();
+        return false;
+    }
+    if (tid < 64) step_pose_wave(st, q, r2, sh);
+    StepShared mine; // the schedule chain's results, in the registers of the lane that computed them
+    if (tid == 64) {
+        step_schedule_chain(st, q, sc, sh, mine);
+        sh->next[NEXT_THR] = mine.thr;
+        sh->next[NEXT_MODE] = 0.0;
+        sh->next[NEXT_IT] = (double)mine.it;
+        sh->next[NEXT_STOP] = mine.stop;
+    }
+    if (hist_row != nullptr && tid >= 128 && tid < 192) fill_history_linear(hist_row, q, r2, tid - 128);
+    __syncthreads();
+    // state update (:231-238) and history row, one entry per lane; nobody waits for it here
+    if (tid < 16) {
+        const double t = sh->T1[tid];
+        const double ti = sh->Tinv[tid];
+        const int improved = sh->improved;
+        st[ST_W_T_C + tid] = t;
+        st[ST_C_T_W + tid] = ti;
+        if (improved) st[ST_BEST_T + tid] = t;
+        if (hist_row != nullptr) hist_row[PICP_H_T + tid] = t;
+    } else if (tid < 22) {
+        if (hist_row != nullptr) hist_row[PICP_H_DX + (tid - 16)] = sh->dx[tid - 16];
+    } else if (tid == 64) {
+        st[ST_THR] = mine.thr;
+        st[ST_LAMBDA] = mine.lam;
+        st[ST_ERR_PREV] = mine.error;
+        st[ST_MEAN_SLOPE] = mine.mean_slope;
+        st[ST_SIGMA_SLOPE] = mine.sigma_slope;
+        st[ST_STUCK] = mine.stuck;
+        st[ST_FLICKER] = mine.flicker;
+        st[ST_IT] = (double)mine.it;
+        st[ST_STOP] = mine.stop;
+        st[ST_MODE] = 0.0;
+        if (mine.ring_slot >= 0) st[ST_RING + mine.ring_slot] = mine.slope;
+        if (mine.improved) {
+            st[ST_BEST_ERR] = mine.error;
+            st[ST_BEST_IT] = (double)(mine.it - 1);
+        }
+        if (hist_row != nullptr) {
+            hist_row[PICP_H_ERROR] = mine.error;
+            hist_row[PICP_H_NUM_INLIERS] = mine.n_inliers;
+            hist_row[PICP_H_KERNEL_THR] = mine.thr;
+            hist_row[PICP_H_DAMPING] = mine.lam;
+            hist_row[PICP_H_N_INSIDE] = q.n_inside;
+            hist_row[PICP_H_DONE] = mine.done;
+            hist_row[PICP_H_N_STAGE1] = q.n1;
+            hist_row[PICP_H_N_STAGE2] = mine.n_stage2;
+            hist_row[PICP_H_USED_STAGE2] = mine.used_stage2;
+            hist_row[PICP_H_MEAN_STAGE1] = mine.mean_stage1;
+        }
+    }
     return true;
 }
 

@@ -127,9 +127,6 @@ __device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const
     constexpr int B = MAX_GRID / GR; // 8 rows per thread
     static_assert(B == 8 && NV <= RW, "load8_pairs_sc1 issues eight loads");
     const int G = gridDim.x;
-#if defined(PICP_STAMPS) && PICP_STAMPS > 1
-    const unsigned long long xt0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* cur = gx.slots + (size_t)(epoch % SLOTS) * G * RW;
     double* old = gx.slots + (size_t)((epoch + SLOTS - 1u) % SLOTS) * G * RW; // the previous exchange's slot
@@ -149,15 +146,9 @@ __device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const
         }
     }
 
-#if defined(PICP_STAMPS) && PICP_STAMPS > 1
-    const unsigned long long xt1 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int pair = threadIdx.x % PW, grp = threadIdx.x / PW;
     __builtin_amdgcn_s_sleep(FIRST_LOOK_DELAY); // see grid_total
 
-#if defined(PICP_STAMPS) && PICP_STAMPS > 1
-    const unsigned long long xt2 = __builtin_amdgcn_s_memrealtime();
-#endif
     const double* base = cur + (size_t)(grp * B) * RW + 2 * pair;
     f64x2 v[B];
 #pragma unroll
@@ -169,9 +160,6 @@ __device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const
             if (grp * B + k >= G) v[k] = f64x2{0.0, 0.0};
     }
 
-#if defined(PICP_STAMPS) && PICP_STAMPS > 1
-    const unsigned long long xt3 = __builtin_amdgcn_s_memrealtime();
-#endif
     unsigned spins = 0;
     for (;;) {
         bool missing = false;
@@ -190,9 +178,6 @@ __device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const
         }
     }
 
-#if defined(PICP_STAMPS) && PICP_STAMPS > 1
-    const unsigned long long xt4 = __builtin_amdgcn_s_memrealtime();
-#endif
     double ax = 0.0, ay = 0.0;
 #pragma unroll
     for (int k = 0; k < B; ++k) {
@@ -209,33 +194,22 @@ __device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const
         lds[wave * RW + 2 * lane + 1] = ay;
     }
 
-#if defined(PICP_STAMPS) && PICP_STAMPS > 1
-    const unsigned long long xt5 = __builtin_amdgcn_s_memrealtime();
-#endif
     __syncthreads();
-#if defined(PICP_STAMPS) && PICP_STAMPS > 1
-    const unsigned long long xt6 = __builtin_amdgcn_s_memrealtime();
-#endif
     double tot = 0.0;
-    if (threadIdx.x < NV) {
+    if (lane < NV) { // every wave: lane t ends with the total of column t
 #pragma unroll
-        for (int w = 0; w < NTR / 64; ++w) tot += lds[w * RW + threadIdx.x];
+        for (int w = 0; w < NTR / 64; ++w) tot += lds[w * RW + lane];
     }
     out = tot;
     // Every workgroup has published into `cur`, hence has finished reading `old`: reset this
     // workgroup's record there; that slot is next used two exchanges from now.
     if (threadIdx.x < PW) store_pair_sc1(old + (size_t)blockIdx.x * RW + 2 * threadIdx.x, sentinel);
-#if defined(PICP_STAMPS) && PICP_STAMPS > 1
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && epoch == 14)
-        printf("exchange 2, wg %d: published %.2f, slept %.2f, first look back %.2f (spins %u), all present %.2f, folded in wave %.2f, barrier %.2f, end %.2f us\n",
-               (int)blockIdx.x, (xt1 - xt0) * 0.01, (xt2 - xt0) * 0.01, (xt3 - xt0) * 0.01, spins, (xt4 - xt0) * 0.01, (xt5 - xt0) * 0.01,
-               (xt6 - xt0) * 0.01, (__builtin_amdgcn_s_memrealtime() - xt0) * 0.01);
-#endif
     return *lds_flag == 0;
 }
 
 // Grid-wide sum of NV values.  `mine`: this workgroup's total of value tid (threads tid < NV).
-// On success every thread with tid < NV of EVERY workgroup holds the same grid total in `out`.
+// On success lane t < NV of every wave of EVERY workgroup holds the same grid total of value t in `out`
+// (with a single workgroup: the lanes that hold `mine`, which block_sum leaves in every wave).
 // Returns false (uniformly over the workgroup) when a wait ran into its bound.
 template <int NV, int B>
 __device__ __forceinline__ bool grid_total(double mine, double& out, const GridExchange& gx, unsigned& epoch,
@@ -474,8 +448,6 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     __shared__ double st[PICP_STATE_DOUBLES];
     __shared__ double lds[NTR];      // workgroup sums
     __shared__ double lds_fold[NTR]; // folds of the exchanged records (a second buffer spares barriers)
-    __shared__ double s1[PICP_S1_DOUBLES];
-    __shared__ double s2[PICP_S2_DOUBLES];
     __shared__ double row[PICP_HIST_STRIDE];
     __shared__ int flag;
     __shared__ StepShared sh;
@@ -513,6 +485,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     // loop entry (src/ProjectiveICP.py:157-171): every workgroup builds its own copy of the state
     if (threadIdx.x == 0) {
         init_state(st, pose0.m, sc.kernel_threshold, sc.damping, sc.num_iterations);
+        init_next(st, &sh);
         flag = 0;
     }
     __syncthreads();
@@ -536,14 +509,16 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
 #else
 #define PICP_STAMP(k)
 #endif
-    while (st[ST_STOP] == 0.0) {
+    // The iteration's inputs come from `sh` (solve_step_lanes): the state block is brought up to date
+    // behind the stages' back.
+    while (sh.next[NEXT_STOP] == 0.0) {
         PICP_STAMP(0);
         double T[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) T[i] = uniform(st[ST_C_T_W + i]);
-        const double thr = uniform(st[ST_THR]);
-        const bool all = (st[ST_MODE] != 0.0);
-        const int it = (int)st[ST_IT];
+        for (int i = 0; i < 12; ++i) T[i] = uniform(sh.Tinv[i]);
+        const double thr = uniform(sh.next[NEXT_THR]);
+        const bool all = (sh.next[NEXT_MODE] != 0.0);
+        const int it = (int)sh.next[NEXT_IT];
 
         Stage1Sums a{0.0, 0u, 0u};
 #pragma unroll
@@ -558,6 +533,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
                 }
             }
         PICP_STAMP(1);
+        double g1;
         {
             constexpr int NV1 = MODERATE ? 4 : 3; // the lean form also counts the lanes with immoderate values
             static_assert(NV1 <= PICP_S1_DOUBLES, "stage-1 record");
@@ -576,19 +552,23 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
                 tot = block_sum<3, NTR, false>(vals, lds);
             }
             PICP_STAMP(2);
-            double g = tot;
-            if (gridDim.x > 1 && !grid_total<NV1, 2>(tot, g, gx, epoch, lds_fold, &flag)) return;
-            if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < NV1) ? g : 0.0;
-            __syncthreads();
+            g1 = tot;
+            if (gridDim.x > 1) {
+                if (!grid_total<NV1, 2>(tot, g1, gx, epoch, lds_fold, &flag)) return;
+            } else {
+                __syncthreads(); // every wave has read its totals before stage 2's sum reuses `lds`
+            }
         }
         PICP_STAMP(3);
-        if (MODERATE && s1[S1_PAD] != 0.0) { // identical in every workgroup
+        // The grid totals sit in lanes 0 .. NV1-1 of every wave: read as scalars, no trip through LDS.
+        if (MODERATE && lane_bcast<S1_PAD>(g1) != 0.0) { // identical in every workgroup
             if (blockIdx.x == 0 && threadIdx.x == 0 && host_state != nullptr) host_state[ST_STOP] = STOP_IMMODERATE;
             return;
         }
-        const double n1 = s1[S1_COUNT]; // identical in every workgroup, so the branch below is grid-uniform
+        const double n1 = lane_bcast<S1_COUNT>(g1); // identical in every workgroup, so the branch below is grid-uniform
+        double g2 = 0.0;                            // :300 when no pair passed stage 1
         if (n1 != 0.0) {
-            const double mean = uniform(s1[S1_SUM_CHI] / n1); // np.mean, src/ProjectiveICP.py:301
+            const double mean = lane_bcast<S1_SUM_CHI>(g1) / n1; // np.mean, src/ProjectiveICP.py:301
             Stage2Sums s;
             s.clear();
             if (KEEP) {
@@ -613,28 +593,27 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
             pack_sets(s, vals);
             const double tot = block_sum<S2_USED, NTR, false>(vals, lds);
             PICP_STAMP(5);
-            double g = 0.0;
-            if (!grid_total<S2_USED, 16>(tot, g, gx, epoch, lds_fold, &flag)) return;
-            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = (threadIdx.x < S2_USED) ? g : 0.0;
-            __syncthreads();
-        } else {
-            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = 0.0; // :300
-            __syncthreads();
+            g2 = tot;
+            if (!grid_total<S2_USED, 16>(tot, g2, gx, epoch, lds_fold, &flag)) return;
+            if ((threadIdx.x & 63) >= S2_USED) g2 = 0.0;
         }
         PICP_STAMP(6);
 
         const bool record = (blockIdx.x == 0 && hist != nullptr && it < hist_rows);
-        const bool advanced = solve_step(st, s1, s2, sc, record ? row : nullptr, &sh);
+        const bool advanced = solve_step_lanes(st, g1, g2, all, sc, record ? row : nullptr, &sh);
 #ifdef PICP_STAMPS
         if (record && threadIdx.x < 6) row[74 + threadIdx.x] = (double)(stamp[threadIdx.x + 1] - stamp[0]) * 0.01;
         if (it == 6)
             for (int k = 0; k < 7; ++k) kept_stamp[k] = stamp[k];
         if (it == 7) kept_stamp[7] = stamp[0]; // = end of iteration 6's solve step
-        __syncthreads();
 #endif
-        if (record && advanced && threadIdx.x < PICP_HIST_STRIDE)
-            hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
+        if (record) { // workgroup 0 only: the row is complete once every lane has passed this barrier
+            __syncthreads();
+            if (advanced && threadIdx.x < PICP_HIST_STRIDE)
+                hist[(size_t)it * PICP_HIST_STRIDE + threadIdx.x] = row[threadIdx.x];
+        }
     }
+    __syncthreads(); // the last tail's writes to the state block
 #ifdef PICP_STAMPS
     if (threadIdx.x == 0 && host_state != nullptr && hist != nullptr) // (one line per workgroup, on the recorded runs only)
         printf("wg %d: %llu %llu %llu %llu %llu %llu %llu %llu\n", (int)blockIdx.x, kept_stamp[0], kept_stamp[1],
