@@ -347,10 +347,22 @@ __device__ __forceinline__ double wave_column_sums(double (&v)[N]) {
     return v[0];
 }
 
+// v[0] + .. + v[N-1] added pairwise ((v0 + v1) + (v2 + v3)) + ..: log2(N) dependent additions instead
+// of N - 1, in an order that depends on N alone.
+template <int N>
+__device__ __forceinline__ double pairwise_sum(double (&v)[N]) {
+#pragma unroll
+    for (int stride = 1; stride < N; stride *= 2) {
+#pragma unroll
+        for (int i = 0; i + stride < N; i += 2 * stride) v[i] += v[i + stride];
+    }
+    return v[0];
+}
+
 // Sums NV per-thread values over a workgroup of NT threads (NT a multiple of 64, <= 1024).
 // lds: at least (NT/64)*64 doubles.  On return lane t < NV of EVERY wave holds the workgroup total
 // of value t (other lanes: unspecified).  Fixed order of additions: wave_column_sums
-// inside each wave, then waves 0,1,2,.. in order.
+// inside each wave, then the waves pairwise.
 // TRAILING_SYNC = false leaves out the final barrier: the caller must not write `lds` again before
 // its next workgroup barrier.
 template <int NV, int NT, bool TRAILING_SYNC = true>
@@ -371,8 +383,10 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
             lds[wave * 64 + (lane >> 1)] = tot; // with 32 values, lanes 2k and 2k+1 hold the total of value k
         __syncthreads();
         if (lane < NV) {
+            double part[NT / 64];
 #pragma unroll
-            for (int w = 0; w < NT / 64; ++w) out += lds[w * 64 + lane];
+            for (int w = 0; w < NT / 64; ++w) part[w] = lds[w * 64 + lane];
+            out = pairwise_sum(part);
         }
     } else {
 #pragma unroll
@@ -382,8 +396,10 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
         }
         __syncthreads();
         if (lane < NV) {
+            double part[NT / 64];
 #pragma unroll
-            for (int w = 0; w < NT / 64; ++w) out += lds[w * 64 + lane];
+            for (int w = 0; w < NT / 64; ++w) part[w] = lds[w * 64 + lane];
+            out = pairwise_sum(part);
         }
     }
     if (TRAILING_SYNC) __syncthreads();
@@ -446,9 +462,7 @@ struct PartialFold {
     __device__ __forceinline__ double finish_in_wave(double* lds) {
         static_assert(CW == 4 || CW == 32, "record widths of the two exchanges");
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < B; ++k) acc += v[k];
+        double acc = pairwise_sum(v);
         if (CW == 4) {
             acc += dpp_move<0x114>(acc); // row_shr:4
             acc += dpp_move<0x118>(acc); // row_shr:8: lanes 12..15 of every row of 16 hold the row's four groups
@@ -463,8 +477,10 @@ struct PartialFold {
         __syncthreads();
         double out = 0.0;
         if (lane < NV) { // every wave: lane t ends with the total of column t
+            double part[NT / 64];
 #pragma unroll
-            for (int w = 0; w < NT / 64; ++w) out += lds[w * CW + lane];
+            for (int w = 0; w < NT / 64; ++w) part[w] = lds[w * CW + lane];
+            out = pairwise_sum(part);
         }
         return out;
     }

@@ -117,8 +117,8 @@ __device__ __forceinline__ void load8_pairs_sc1(const double* p, f64x2 (&v)[8]) 
 // grid_total for the 32-double records, in 16-byte pieces.  Thread (grp, pair) owns the column pair
 // (2 pair, 2 pair + 1) of the eight rows 8 grp .. 8 grp + 7: 32 groups cover 256 rows.  Rows past the
 // grid are read all the same (the slots are allocated for 256 rows and eight more) and dropped.
-// Fixed order of additions: a thread's rows in order, then the four groups of a wave (lane swaps),
-// then the waves in order.
+// Fixed order of additions: a thread's rows pairwise, then the four groups of a wave (lane swaps),
+// then the waves pairwise.
 template <int NV>
 __device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const GridExchange& gx, unsigned& epoch,
                                                  double* lds, int* lds_flag) {
@@ -178,12 +178,13 @@ __device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const
         }
     }
 
-    double ax = 0.0, ay = 0.0;
+    double vx[B], vy[B];
 #pragma unroll
     for (int k = 0; k < B; ++k) {
-        ax += v[k].x;
-        ay += v[k].y;
+        vx[k] = v[k].x;
+        vy[k] = v[k].y;
     }
+    double ax = pairwise_sum(vx), ay = pairwise_sum(vy);
     // the four row groups of a wave sit 16 lanes apart
     ax = halve_bit4(ax, ax);
     ay = halve_bit4(ay, ay);
@@ -197,8 +198,10 @@ __device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const
     __syncthreads();
     double tot = 0.0;
     if (lane < NV) { // every wave: lane t ends with the total of column t
+        double part[NTR / 64];
 #pragma unroll
-        for (int w = 0; w < NTR / 64; ++w) tot += lds[w * RW + lane];
+        for (int w = 0; w < NTR / 64; ++w) part[w] = lds[w * RW + lane];
+        tot = pairwise_sum(part);
     }
     out = tot;
     // Every workgroup has published into `cur`, hence has finished reading `old`: reset this
