@@ -47,6 +47,7 @@ constexpr int R_MAX = 16;                // correspondences per thread
 constexpr int R_KEEP_MAX = 8;            // up to here LDS also keeps stage 1's chi and 1/z for stage 2
 constexpr int SLOTS = 3;
 constexpr int FIRST_LOOK_DELAY = 16;      // s_sleep units (64 clocks) between publishing and the first poll
+constexpr int FIRST_LOOK_DELAY_WIDE = 12; // the same for the 32-double records (swept 0 .. 20 for both: flat within 0.1 us from 12 to 16, 0.3 - 0.7 us worse at 0 .. 8)
 constexpr int MAX_DEVICES = 64;           // per-device bookkeeping of kernel attributes
 constexpr int SINGLE_WG_MAX = 4 * NTR;    // inputs up to here run as one workgroup (no exchange)
 constexpr int MAX_GRID = 256;            // rows one fold covers with all of a thread's loads in flight
@@ -147,7 +148,7 @@ __device__ __forceinline__ bool grid_total_pairs(double mine, double& out, const
     }
 
     const int pair = threadIdx.x % PW, grp = threadIdx.x / PW;
-    __builtin_amdgcn_s_sleep(FIRST_LOOK_DELAY); // see grid_total
+    __builtin_amdgcn_s_sleep(FIRST_LOOK_DELAY_WIDE); // see grid_total
 
     const double* base = cur + (size_t)(grp * B) * RW + 2 * pair;
     f64x2 v[B];
