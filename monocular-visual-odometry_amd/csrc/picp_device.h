@@ -347,6 +347,21 @@ __device__ __forceinline__ double wave_column_sums(double (&v)[N]) {
     return v[0];
 }
 
+// Wave-wide sums of four values at once: two halving steps (lane bits 5 and 4) leave value k's partial
+// sums in the 16 lanes 16 k .. 16 k + 15, four butterfly steps inside the rows of 16 finish them.
+// Every lane of row k returns the wave's total of value k.  21 instructions instead of the 72 of four
+// separate butterflies.  Fixed order of additions.
+__device__ __forceinline__ double wave_sums4(double v0, double v1, double v2, double v3) {
+    const double x = halve_bit5(v0, v2); // lanes < 32: value 0, lanes >= 32: value 2
+    const double y = halve_bit5(v1, v3); //             value 1,              value 3
+    double z = halve_bit4(x, y);         // rows of 16 lanes: values 0, 1, 2, 3
+    z += dpp_move<0x140>(z); // row_mirror
+    z += dpp_move<0x141>(z); // row_half_mirror
+    z += dpp_move<0x4E>(z);  // quad_perm [2,3,0,1]
+    z += dpp_move<0xB1>(z);  // quad_perm [1,0,3,2]
+    return z;
+}
+
 // v[0] + .. + v[N-1] added pairwise ((v0 + v1) + (v2 + v3)) + ..: log2(N) dependent additions instead
 // of N - 1, in an order that depends on N alone.
 template <int N>
@@ -381,6 +396,17 @@ __device__ __forceinline__ double block_sum(const double (&vals)[NV], double* ld
             lds[wave * 64 + lane] = tot;
         else if ((lane & 1) == 0)
             lds[wave * 64 + (lane >> 1)] = tot; // with 32 values, lanes 2k and 2k+1 hold the total of value k
+        __syncthreads();
+        if (lane < NV) {
+            double part[NT / 64];
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) part[w] = lds[w * 64 + lane];
+            out = pairwise_sum(part);
+        }
+    } else if (NV <= 4) {
+        const double s = wave_sums4(vals[0], NV > 1 ? vals[NV > 1 ? 1 : 0] : 0.0, NV > 2 ? vals[NV > 2 ? 2 : 0] : 0.0,
+                                    NV > 3 ? vals[NV > 3 ? 3 : 0] : 0.0);
+        if ((lane & 15) == 0 && (lane >> 4) < NV) lds[wave * 64 + (lane >> 4)] = s; // row k holds value k
         __syncthreads();
         if (lane < NV) {
             double part[NT / 64];

@@ -45,6 +45,7 @@ constexpr int NTR = 512;                 // eight waves: two per SIMD
 constexpr int RW = PICP_S2_DOUBLES;      // doubles per exchange record (both stages use one slot layout)
 constexpr int R_MAX = 16;                // correspondences per thread
 constexpr int R_KEEP_MAX = 8;            // up to here LDS also keeps stage 1's chi and 1/z for stage 2
+constexpr int R_LEAN_MAX = 6;            // up to here the lean form of stage 2 pays (at 8 it spills: 12.7 against 12.45 us per iteration)
 constexpr int SLOTS = 3;
 constexpr int FIRST_LOOK_DELAY = 16;      // s_sleep units (64 clocks) between publishing and the first poll
 constexpr int FIRST_LOOK_DELAY_WIDE = 12; // the same for the 32-double records (swept 0 .. 20 for both: flat within 0.1 us from 12 to 16, 0.3 - 0.7 us worse at 0 .. 8)
@@ -496,6 +497,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
 
     unsigned epoch = 0;
 #ifdef PICP_STAMPS
+    const unsigned long long core0 = __builtin_amdgcn_s_memtime(), wall0 = __builtin_amdgcn_s_memrealtime();
     // Diagnostic build only: clock stamps of workgroup 0 at the segment boundaries of an iteration,
     // left in the unused tail of the history row (entries 74 .. 79, microseconds since the iteration
     // began: stage 1, its workgroup sum, its exchange, stage 2, its workgroup sum, its exchange).
@@ -619,6 +621,12 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     }
     __syncthreads(); // the last tail's writes to the state block
 #ifdef PICP_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0 && host_state != nullptr && hist != nullptr) {
+        // the shader clock the loop actually ran at: core-clock counter against the constant 100 MHz one
+        const unsigned long long core1 = __builtin_amdgcn_s_memtime(), wall1 = __builtin_amdgcn_s_memrealtime();
+        printf("shader clock during the loop: %.0f MHz (%llu core cycles in %.1f us)\n",
+               (double)(core1 - core0) / ((double)(wall1 - wall0) * 0.01), core1 - core0, (double)(wall1 - wall0) * 0.01);
+    }
     if (threadIdx.x == 0 && host_state != nullptr && hist != nullptr) // (one line per workgroup, on the recorded runs only)
         printf("wg %d: %llu %llu %llu %llu %llu %llu %llu %llu\n", (int)blockIdx.x, kept_stamp[0], kept_stamp[1],
                kept_stamp[2], kept_stamp[3], kept_stamp[4], kept_stamp[5], kept_stamp[6], kept_stamp[7]);
@@ -890,13 +898,13 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
                             hipEvent_t e1) {
     const CameraK c = camera_of(cam);
     GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
-    // The lean form where it exists (it differs only where stage 1's results are kept on chip), unless
-    // a recent loop met immoderate values or the camera matrix itself is not moderate.
-    bool lean = (R <= R_KEEP_MAX) && ctx->full_select_calls == 0;
+    // The lean form where it pays (up to R_LEAN_MAX correspondences per thread), unless a recent loop met
+    // immoderate values or the camera matrix itself is not moderate.
+    bool lean = (R <= R_LEAN_MAX) && ctx->full_select_calls == 0;
     for (int i = 0; i < 9; ++i) lean = lean && fabs(cam->K[i]) < 0x1p199; // moderate(), as the kernel tests its values
-    if ((R <= R_KEEP_MAX) && ctx->full_select_calls > 0) ctx->full_select_calls -= 1;
-    auto kern = is_pinhole(cam->K) ? (lean ? icp_resident_kernel<R, true, (R <= R_KEEP_MAX)> : icp_resident_kernel<R, true, false>)
-                                   : (lean ? icp_resident_kernel<R, false, (R <= R_KEEP_MAX)> : icp_resident_kernel<R, false, false>);
+    if ((R <= R_LEAN_MAX) && ctx->full_select_calls > 0) ctx->full_select_calls -= 1;
+    auto kern = is_pinhole(cam->K) ? (lean ? icp_resident_kernel<R, true, (R <= R_LEAN_MAX)> : icp_resident_kernel<R, true, false>)
+                                   : (lean ? icp_resident_kernel<R, false, (R <= R_LEAN_MAX)> : icp_resident_kernel<R, false, false>);
     constexpr unsigned kept_bytes = R * (R <= R_KEEP_MAX ? 4 : 2) * NTR * sizeof(double); // u, v (, chi, 1/z)
     if (kept_bytes > 48 * 1024) { // above the default dynamic-LDS allowance: raise it once per kernel and device
         static bool raised[4][MAX_DEVICES] = {};
