@@ -1,6 +1,9 @@
 // Probe: one-way latency of a flag handed from one workgroup to another through device memory, for a
 // pair of workgroups on the same XCD and a pair on different XCDs (each XCD has its own L2), with
 // device-scope accesses.  Also prints which XCD every workgroup of a small grid landed on.
+// (Workgroup-scope accesses are not an alternative inside an XCD: the flag never becomes visible to
+// the other compute unit -- the loads are served by its own first-level cache -- tried once, the
+// run had to be killed.)
 // Build: hipcc -O2 --offload-arch=gfx950 tools/hop_probe.hip -o tools/hop_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -23,10 +26,10 @@ __global__ void bounce(unsigned* ping, unsigned* pong, int a, int b, int n, unsi
         if (first) {
             __hip_atomic_store(ping, (unsigned)i, __ATOMIC_RELAXED, SCOPE);
             unsigned spins = 0;
-            while (__hip_atomic_load(pong, __ATOMIC_RELAXED, SCOPE) != (unsigned)i && ++spins < (1u << 22)) {}
+            while (__hip_atomic_load(pong, __ATOMIC_RELAXED, SCOPE) != (unsigned)i && ++spins < (1u << 16)) {}
         } else {
             unsigned spins = 0;
-            while (__hip_atomic_load(ping, __ATOMIC_RELAXED, SCOPE) != (unsigned)i && ++spins < (1u << 22)) {}
+            while (__hip_atomic_load(ping, __ATOMIC_RELAXED, SCOPE) != (unsigned)i && ++spins < (1u << 16)) {}
             __hip_atomic_store(pong, (unsigned)i, __ATOMIC_RELAXED, SCOPE);
         }
     }
