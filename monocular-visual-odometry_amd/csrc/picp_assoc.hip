@@ -131,6 +131,7 @@ __global__ __launch_bounds__(ANT) void assoc_scan_kernel(const double* __restric
 // query row with more than HASH_MAX_DUP matches, raises a flag and the host falls back to the
 // all-pairs scan, which has no such limit.
 constexpr int HASH_MAX_PROBE = 2048;
+constexpr int HASH_LOOK = 4; // table entries a counting walk fetches per step
 constexpr int HASH_MAX_DUP = 32;
 
 // Returns false for a row that contains NaN.
@@ -248,29 +249,52 @@ __device__ __forceinline__ bool verify_candidates(int64_t cand, const double* q_
     const int g = lane / P, part = lane - g * P;
     const unsigned long long want = __ballot(cand >= 0);
     bool equal = false;
-    for (int base = 0; base < 64; base += G) {
-        const unsigned long long chunk = (G >= 64) ? ~0ull : (((1ull << G) - 1ull) << base);
-        if ((want & chunk) == 0ull) continue; // uniform: no candidate among these queries
-        const int ql = base + g;              // the query this lane helps with
-        const int src = ql < 64 ? ql : 63;
-        const int64_t j = __shfl(cand, src, 64);
-        bool part_equal = true;
-        const bool active = (g < G) && (ql < 64) && (j >= 0);
-        if (active) {
-            const double* qrow = q_wave + src * DS;
-            if (WIDE) {
-                const double2 v = reinterpret_cast<const double2*>(app2 + j * D)[part];
-                part_equal = (qrow[2 * part] == v.x) && (qrow[2 * part + 1] == v.y);
-            } else {
-                part_equal = (qrow[part] == app2[j * D + part]);
+    // The loads of up to VERIFY_BATCH steps are issued before the first comparison: the steps are
+    // independent random reads, and one memory round trip per step would make a wave with candidates
+    // in all its lanes wait six round trips (D = 10) where one does.
+    constexpr int VERIFY_BATCH = 8;
+    for (int base0 = 0; base0 < 64; base0 += G * VERIFY_BATCH) {
+        double2 v[VERIFY_BATCH];
+        bool active[VERIFY_BATCH];
+#pragma unroll
+        for (int c = 0; c < VERIFY_BATCH; ++c) {
+            const int base = base0 + c * G;
+            active[c] = false;
+            v[c] = double2{0.0, 0.0};
+            if (base >= 64) continue;
+            const unsigned long long chunk = (G >= 64) ? ~0ull : (((1ull << G) - 1ull) << base);
+            if ((want & chunk) == 0ull) continue; // uniform: no candidate among these queries
+            const int ql = base + g;              // the query this lane helps with
+            const int src = ql < 64 ? ql : 63;
+            const int64_t j = __shfl(cand, src, 64);
+            active[c] = (g < G) && (ql < 64) && (j >= 0);
+            if (active[c]) {
+                if (WIDE)
+                    v[c] = reinterpret_cast<const double2*>(app2 + j * D)[part];
+                else
+                    v[c].x = app2[j * D + part];
             }
         }
-        // a query's row is equal when none of its P lanes saw a difference
-        const unsigned long long differs = __ballot(active && !part_equal);
-        const int mine = lane - base; // this lane's place among the chunk's queries
-        if (mine >= 0 && mine < G && cand >= 0) {
-            const unsigned long long group = ((P >= 64) ? ~0ull : ((1ull << P) - 1ull)) << (mine * P);
-            equal = (differs & group) == 0ull;
+#pragma unroll
+        for (int c = 0; c < VERIFY_BATCH; ++c) {
+            const int base = base0 + c * G;
+            if (base >= 64) continue;
+            const unsigned long long chunk = (G >= 64) ? ~0ull : (((1ull << G) - 1ull) << base);
+            if ((want & chunk) == 0ull) continue;
+            const int ql = base + g;
+            const int src = ql < 64 ? ql : 63;
+            bool part_equal = true;
+            if (active[c]) {
+                const double* qrow = q_wave + src * DS;
+                part_equal = WIDE ? ((qrow[2 * part] == v[c].x) && (qrow[2 * part + 1] == v[c].y)) : (qrow[part] == v[c].x);
+            }
+            // a query's row is equal when none of its P lanes saw a difference
+            const unsigned long long differs = __ballot(active[c] && !part_equal);
+            const int mine = lane - base; // this lane's place among the chunk's queries
+            if (mine >= 0 && mine < G && cand >= 0) {
+                const unsigned long long group = ((P >= 64) ? ~0ull : ((1ull << P) - 1ull)) << (mine * P);
+                equal = (differs & group) == 0ull;
+            }
         }
     }
     return equal;
@@ -299,25 +323,39 @@ __global__ __launch_bounds__(ANT) void hash_count_kernel(const double* __restric
     uint64_t slot = h & mask;
     int probe = 0;
     bool complete = true;
+    // A walk is a chain of dependent random reads, and the wave stays in it until its longest walk has
+    // ended (about ten entries at half load); HASH_LOOK entries are therefore fetched per step, all in
+    // flight together (they mostly share a cache line), which cuts the chain to two or three steps.
     while (__ballot(walking) != 0ull) {
-        int64_t cand = -1;
+        unsigned long long e[HASH_LOOK];
         if (walking) {
-            const unsigned long long e = table[slot];
-            if (e == 0ull) {
-                walking = false;
-            } else {
-                if ((e >> 32) == tag) cand = (int64_t)(e & 0xffffffffull) - 1;
-                slot = (slot + 1) & mask;
-                if (++probe >= HASH_MAX_PROBE) {
+#pragma unroll
+            for (int k = 0; k < HASH_LOOK; ++k) e[k] = table[(slot + k) & mask];
+        }
+        int64_t cand[HASH_LOOK];
+#pragma unroll
+        for (int k = 0; k < HASH_LOOK; ++k) {
+            cand[k] = -1;
+            if (walking) {
+                if (e[k] == 0ull) {
                     walking = false;
-                    complete = false;
+                } else {
+                    if ((e[k] >> 32) == tag) cand[k] = (int64_t)(e[k] & 0xffffffffull) - 1;
+                    if (++probe >= HASH_MAX_PROBE) {
+                        walking = false;
+                        complete = false;
+                    }
                 }
             }
         }
-        if (__ballot(cand >= 0) != 0ull) {
-            if (verify_candidates<WIDE>(cand, q_wave, DS, app2, D)) {
-                fst = (cnt == 0 || cand < fst) ? cand : fst;
-                cnt += 1;
+        slot = (slot + HASH_LOOK) & mask;
+#pragma unroll
+        for (int k = 0; k < HASH_LOOK; ++k) {
+            if (__ballot(cand[k] >= 0) != 0ull) {
+                if (verify_candidates<WIDE>(cand[k], q_wave, DS, app2, D)) {
+                    fst = (cnt == 0 || cand[k] < fst) ? cand[k] : fst;
+                    cnt += 1;
+                }
             }
         }
     }
