@@ -371,9 +371,13 @@ __global__ __launch_bounds__(ANT) void hash_emit_kernel(const double* __restrict
                                                         const int64_t* __restrict__ count,
                                                         const int64_t* __restrict__ first,
                                                         const int64_t* __restrict__ offset, int64_t* __restrict__ idx1,
-                                                        int64_t* __restrict__ idx2, int64_t capacity) {
+                                                        int64_t* __restrict__ idx2, int64_t capacity,
+                                                        const int* __restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
     if (i >= N1) return;
+    // The count kernel gave up (long walks or very many equal rows): the host repeats the association with
+    // the all-pairs scan, and the counts here may be huge or incomplete -- emit nothing.
+    if (*flag != 0) return;
     const int64_t c = count[i];
     if (c == 0) return;
     const int64_t o = offset[i];
@@ -633,6 +637,21 @@ static int associate_pass(picp_ctx* ctx, bool hashed, const double* app1, int64_
     hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count, N1,
                        (const int64_t*)ctx->assoc_blocksum, nb, ctx->assoc_offset);
     PICP_HIP_CHECK(hipGetLastError());
+    // The pairs are emitted before the host knows their number: the emit kernels write nothing beyond
+    // `capacity`, so one wait at the end serves the count, the fallback flag and the index lists (a second
+    // wait between counting and emitting costs more than an emit whose output is then thrown away).
+    if (capacity > 0) {
+        if (hashed)
+            hipLaunchKernelGGL(hash_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, D,
+                               (const unsigned long long*)ctx->assoc_table, mask, (const int64_t*)ctx->assoc_count,
+                               (const int64_t*)ctx->assoc_first, (const int64_t*)ctx->assoc_offset, idx1, idx2,
+                               capacity, (const int*)flag);
+        else
+            hipLaunchKernelGGL(assoc_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, N2, D,
+                               (const int64_t*)ctx->assoc_count, (const int64_t*)ctx->assoc_first,
+                               (const int64_t*)ctx->assoc_offset, idx1, idx2, capacity);
+        PICP_HIP_CHECK(hipGetLastError());
+    }
     int64_t* h = reinterpret_cast<int64_t*>(ctx->pinned);
     h[1] = 0;
     PICP_HIP_CHECK(hipMemcpyAsync(h, ctx->assoc_offset + N1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -646,19 +665,6 @@ static int associate_pass(picp_ctx* ctx, bool hashed, const double* app1, int64_
     if (h[0] > capacity) {
         set_error("picp_associate: %lld pairs found, index arrays hold %lld", (long long)h[0], (long long)capacity);
         return PICP_ERR_CAPACITY;
-    }
-    if (h[0] > 0) {
-        if (hashed)
-            hipLaunchKernelGGL(hash_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, D,
-                               (const unsigned long long*)ctx->assoc_table, mask, (const int64_t*)ctx->assoc_count,
-                               (const int64_t*)ctx->assoc_first, (const int64_t*)ctx->assoc_offset, idx1, idx2,
-                               capacity);
-        else
-            hipLaunchKernelGGL(assoc_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, N2, D,
-                               (const int64_t*)ctx->assoc_count, (const int64_t*)ctx->assoc_first,
-                               (const int64_t*)ctx->assoc_offset, idx1, idx2, capacity);
-        PICP_HIP_CHECK(hipGetLastError());
-        PICP_HIP_CHECK(hipStreamSynchronize(s));
     }
     return PICP_OK;
 }
