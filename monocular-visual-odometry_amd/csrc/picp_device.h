@@ -704,7 +704,6 @@ struct MemRecord {
     __device__ __forceinline__ double at() const { return p[I]; }
     __device__ __forceinline__ double dyn(int i) const { return p[i]; }
 };
-struct LaneRecord;
 
 // The entries of the stage records that the tail's scalar decisions need.
 struct StageScalars {

@@ -755,8 +755,6 @@ __global__ __launch_bounds__(NTB, (R <= BATCHED_THREE_PER_CU_MAX_R) ? 3 : 2) voi
     picp_schedule sc, picp_result* __restrict__ results, double* __restrict__ hist, int hist_rows) {
     __shared__ double st[PICP_STATE_DOUBLES];
     __shared__ double lds[NTB];
-    __shared__ double s1[PICP_S1_DOUBLES];
-    __shared__ double s2[PICP_S2_DOUBLES];
     __shared__ StepShared sh;
     extern __shared__ double dyn[]; // u, v as [R][2][NTB], then chi, 1/z of stage 1 as [R][2][NTB]
     double* muv = dyn;
@@ -782,7 +780,10 @@ __global__ __launch_bounds__(NTB, (R <= BATCHED_THREE_PER_CU_MAX_R) ? 3 : 2) voi
         }
         return;
     }
-    if (threadIdx.x == 0) init_state(st, poses0 + (size_t)prob * 16, sc.kernel_threshold, sc.damping, sc.num_iterations);
+    if (threadIdx.x == 0) {
+        init_state(st, poses0 + (size_t)prob * 16, sc.kernel_threshold, sc.damping, sc.num_iterations);
+        init_next(st, &sh);
+    }
     double rx[R], ry[R], rz[R];
     int mine = 0;
 #pragma unroll
@@ -802,13 +803,15 @@ __global__ __launch_bounds__(NTB, (R <= BATCHED_THREE_PER_CU_MAX_R) ? 3 : 2) voi
     __syncthreads();
     double* myhist = (hist != nullptr) ? hist + (size_t)prob * hist_rows * PICP_HIST_STRIDE : nullptr;
 
-    while (st[ST_STOP] == 0.0) {
+    // As in the grid-wide loop: the workgroup sums stay in registers (lane t of every wave holds entry t)
+    // and the iteration's inputs come from `sh` (solve_step_lanes).
+    while (sh.next[NEXT_STOP] == 0.0) {
         double T[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) T[i] = uniform(st[ST_C_T_W + i]);
-        const double thr = uniform(st[ST_THR]);
-        const bool all = (st[ST_MODE] != 0.0);
-        const int it = (int)st[ST_IT];
+        for (int i = 0; i < 12; ++i) T[i] = uniform(sh.Tinv[i]);
+        const double thr = uniform(sh.next[NEXT_THR]);
+        const bool all = (sh.next[NEXT_MODE] != 0.0);
+        const int it = (int)sh.next[NEXT_IT];
 
         Stage1Sums a{0.0, 0u, 0u};
 #pragma unroll
@@ -820,15 +823,15 @@ __global__ __launch_bounds__(NTB, (R <= BATCHED_THREE_PER_CU_MAX_R) ? 3 : 2) voi
                 kept[(r * KS + 0) * NTB + threadIdx.x] = keep[0];
                 if (KS == 2) kept[(r * KS + 1) * NTB + threadIdx.x] = keep[1];
             }
+        double g1;
         {
             const double vals[3] = {a.sum_chi, (double)a.n1, (double)a.n_inside};
-            const double tot = block_sum<3, NTB>(vals, lds);
-            if (threadIdx.x < PICP_S1_DOUBLES) s1[threadIdx.x] = (threadIdx.x < 3) ? tot : 0.0;
-            __syncthreads();
+            g1 = block_sum<3, NTB>(vals, lds); // (trailing barrier: stage 2's sum reuses `lds`)
         }
-        const double n1 = s1[S1_COUNT];
+        const double n1 = lane_bcast<S1_COUNT>(g1);
+        double g2 = 0.0; // :300 when no pair passed stage 1
         if (n1 != 0.0) {
-            const double mean = uniform(s1[S1_SUM_CHI] / n1); // np.mean, src/ProjectiveICP.py:301
+            const double mean = lane_bcast<S1_SUM_CHI>(g1) / n1; // np.mean, src/ProjectiveICP.py:301
             Stage2Sums s;
             s.clear();
 #pragma unroll
@@ -842,20 +845,17 @@ __global__ __launch_bounds__(NTB, (R <= BATCHED_THREE_PER_CU_MAX_R) ? 3 : 2) voi
                 }
             double vals[S2_USED];
             pack_sets(s, vals);
-            const double tot = block_sum<S2_USED, NTB>(vals, lds);
-            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = (threadIdx.x < S2_USED) ? tot : 0.0;
-            __syncthreads();
-        } else {
-            if (threadIdx.x < PICP_S2_DOUBLES) s2[threadIdx.x] = 0.0; // :300
-            __syncthreads();
+            g2 = block_sum<S2_USED, NTB, false>(vals, lds); // the tail's barrier comes before `lds` is written again
+            if ((threadIdx.x & 63) >= S2_USED) g2 = 0.0;
         }
         double* row = (myhist != nullptr && it < hist_rows) ? myhist + (size_t)it * PICP_HIST_STRIDE : nullptr;
         // The tail is a latency chain on single lanes while the other workgroups of the CU stream
         // through their stages: its waves go first whenever they can issue (2 % on 4 096 x 2 048).
         __builtin_amdgcn_s_setprio(3);
-        (void)solve_step(st, s1, s2, sc, row, &sh);
+        (void)solve_step_lanes(st, g1, g2, all, sc, row, &sh);
         __builtin_amdgcn_s_setprio(0);
     }
+    __syncthreads(); // the last tail's writes to the state block
     if (threadIdx.x == 0) {
         picp_result r;
         const bool valid = (st[ST_IT] > 0.0) && !(st[ST_BEST_ERR] > 5.0); // src/ProjectiveICP.py:249
