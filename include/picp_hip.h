@@ -158,7 +158,8 @@ int picp_profile_run(picp_ctx* ctx, const double* u, const double* v, const doub
  * enqueues; it accepts what picp_run executes as a single launch (non-empty input within
  * picp_resident_capacity, or larger 16-byte aligned arrays; at least one iteration) and refuses
  * everything else with PICP_ERR_INVALID.  picp_run_collect waits for the loop of that slot and fills
- * `result` as picp_run does; PICP_ERR_RETRY means the launch gave up at an exchange (shared device)
+ * `result` as picp_run does; PICP_ERR_RETRY means the launch computed nothing -- it gave up at an
+ * exchange (shared device), or it met values outside the lean form's range (picp_immoderate_exits) --
  * and the caller should run that loop again with picp_run.  state and hist must stay untouched until
  * the slot has been collected, and a slot must be collected before it is used again.  Loops on one
  * ctx execute in the order they were enqueued. */
