@@ -36,12 +36,12 @@ struct picp_ctx {
     double* pinned; // host-pinned staging for small read-backs
     double* noalloc; // this device's address of the static workspace of picp_linearize_noalloc
     // register-resident loop (picp_resident.hip)
-    double* rslots;                // [resident_slot_rows][PICP_S2_DOUBLES] exchange records: 3 slots of a launch's grid
+    double* rslots;                // [2][resident_slot_rows][PICP_S2_DOUBLES] exchange records: two sets of 3 slots of a launch's grid
+    int slot_set;                  // the set the next single-launch loop exchanges through
+    int slots_clean[2];            // the set holds sentinels everywhere
     int64_t resident_limit;        // largest M the resident loop is used for (0: never)
     unsigned resident_spin_limit;  // polls before a waiting workgroup abandons the launch
     int resident_aborts;           // launches abandoned so far (each was repeated with the streaming kernels)
-    int resident_clean_grid;       // exchange slots hold sentinels for launches of up to this many workgroups
-    int resident_last_grid;        // workgroups of the last launch
     int abort_streak;              // consecutive single-launch loops that gave up
     int single_launch_holdoff;     // picp_run calls that still go straight to the stage launches after a streak
     int64_t persistent_limit;      // largest M the streaming single-launch loop is used for (0: never)
@@ -94,7 +94,6 @@ int sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const double
 // picp_resident.hip
 int64_t resident_capacity(const picp_ctx* ctx);
 int resident_slot_rows(const picp_ctx* ctx); // records to allocate for the in-kernel exchange (rslots)
-void resident_refill(picp_ctx* ctx);
 int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
                      const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,

@@ -70,7 +70,7 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     if (e == hipSuccess) e = hipMemset(ctx->scratch, 0, sizeof(double) * SCR_DOUBLES);
     if (e == hipSuccess) e = hipMalloc(&ctx->arrive, sizeof(unsigned) * 64);
     if (e == hipSuccess) e = hipMemset(ctx->arrive, 0, sizeof(unsigned) * 64);
-    if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * PICP_S2_DOUBLES * resident_slot_rows(ctx));
+    if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * 2 * PICP_S2_DOUBLES * resident_slot_rows(ctx));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->loop_done, hipEventDisableTiming);
     for (int k = 0; k < PICP_ASYNC_SLOTS && e == hipSuccess; ++k)
         e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
@@ -124,8 +124,8 @@ int picp_destroy(picp_ctx* ctx) {
 int picp_set_stream(picp_ctx* ctx, void* stream) {
     PICP_REQUIRE(ctx != nullptr, "picp_set_stream: null ctx");
     if (ctx->stream == static_cast<hipStream_t>(stream)) return PICP_OK;
-    // A refill of the exchange slots may still be pending on the old stream; nothing orders it with work on
-    // the new one, and a late refill would wipe records of a loop that runs there.  Wait for it.
+    // A single-launch loop may still be running on the old stream, and it cleans the set of exchange slots
+    // that the next loop uses: nothing orders that with work on the new stream.  Wait for it.
     DeviceGuard g(ctx->device);
     PICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->stream = static_cast<hipStream_t>(stream);

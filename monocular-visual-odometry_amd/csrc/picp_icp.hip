@@ -422,12 +422,10 @@ static void result_from_state(const double* h, const double* w_T_c0_host, picp_r
     result->best_error = h[ST_BEST_ERR];
 }
 
-// Waits for a single-launch loop that has just been enqueued.  The exchange slots are restored for
-// the next loop by a small kernel enqueued behind it; the host waits for an event recorded between
-// the two, so that launch is issued while the loop runs and is not waited for.
+// Waits for a single-launch loop that has just been enqueued (for an event behind it, not for the
+// stream).
 static int wait_for_loop(picp_ctx* ctx) {
     PICP_HIP_CHECK(hipEventRecord(ctx->loop_done, ctx->stream));
-    resident_refill(ctx);
     PICP_HIP_CHECK(hipEventSynchronize(ctx->loop_done)); // (polling hipEventQuery instead measured slower)
     return PICP_OK;
 }
@@ -923,7 +921,6 @@ int picp_run_enqueue(picp_ctx* ctx, const double* u, const double* v, const doub
                                                 (int)hist_rows, host_state, nullptr, nullptr);
     if (rc != PICP_OK) return rc;
     PICP_HIP_CHECK(hipEventRecord(ctx->slot_done[slot], ctx->stream));
-    resident_refill(ctx);
     return PICP_OK;
 }
 

@@ -55,7 +55,9 @@ constexpr int MAX_GRID = 256;            // rows one fold covers with all of a t
 constexpr unsigned long long SENTINEL_BITS = 0xFFF8C0DEC0DE5EEDull; // a NaN payload arithmetic never produces
 
 struct GridExchange {
-    double* slots;       // [SLOTS][gridDim.x][RW]
+    double* slots;       // [SLOTS][gridDim.x][RW]: the set of slots this launch exchanges through
+    double* restore;     // the other set, which this launch fills with sentinels for the next launch (or null)
+    int restore_doubles; // its length
     unsigned spin_limit; // re-reads before a waiting thread gives up
 };
 
@@ -74,9 +76,9 @@ struct StartPose {
     double m[16];
 };
 
-// Every record of every slot holds the sentinel.  Run before a launch whose slots are not known to
-// be clean, and again (asynchronously) after a completed loop, so that the next loop of the same
-// shape starts without waiting for it.
+// Every record of a set of slots (or of a rank's exchange memory) holds the sentinel.  Run before a
+// launch whose set is not known to be clean: the first launch of a context; after that the launches
+// clean each other's sets (restore_other_set).
 __global__ void resident_fill_kernel(double* slots, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) slots[i] = __longlong_as_double((long long)SENTINEL_BITS);
@@ -114,6 +116,19 @@ __device__ __forceinline__ void load8_pairs_sc1(const double* p, f64x2 (&v)[8]) 
         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
         : "v"(p)
         : "memory");
+}
+
+// Two sets of slots alternate between the launches of a context: while a launch exchanges through one
+// set, it leaves the other one full of sentinels for the launch after it -- in its prologue, behind its
+// first loads, where the stores cost nothing -- instead of a fill kernel between every two loops
+// (4.5 us of kernel plus a launch gap per loop).  The previous launch, which used that set, has ended
+// (stream order), and the stores have landed when this launch ends.  Spread over all workgroups.
+__device__ __forceinline__ void restore_other_set(const GridExchange& gx) {
+    if (gx.restore == nullptr) return;
+    const f64x2 sentinel = {__longlong_as_double((long long)SENTINEL_BITS), __longlong_as_double((long long)SENTINEL_BITS)};
+    const int pairs = gx.restore_doubles / 2;
+    for (int i = (int)blockIdx.x + (int)gridDim.x * (int)threadIdx.x; i < pairs; i += (int)gridDim.x * (int)blockDim.x)
+        store_pair_sc1(gx.restore + 2 * (size_t)i, sentinel);
 }
 
 // grid_total for the 32-double records, in 16-byte pieces.  Thread (grp, pair) owns the column pair
@@ -466,6 +481,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
 
     // correspondence (r, workgroup, thread) -> index (r * grid + workgroup) * NTR + thread: every load
     // instruction of a wave reads 64 consecutive doubles
+    restore_other_set(gx);
     double rx[R], ry[R], rz[R];
     const int64_t first = (int64_t)blockIdx.x * NTR + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * NTR;
@@ -666,6 +682,7 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
     CorrStream<2, NTR, false> fwd;
     CorrStream<2, NTR, REVERSE> rev; // stage 2's direction: see stage2_reverse()
     fwd.start(u, v, x, y, z, M);
+    restore_other_set(gx);
     if (threadIdx.x == 0) {
         init_state(st, pose0.m, sc.kernel_threshold, sc.damping, sc.num_iterations);
         flag = 0;
@@ -882,9 +899,27 @@ static int resident_grid(const picp_ctx* ctx) {
     return (ctx->grid_limit > 0 && ctx->grid_limit < g) ? ctx->grid_limit : g;
 }
 
-// Three slots of up to MAX_GRID records, read in blocks of eight records that may reach past a
-// slot's last record (grid_total_pairs).
+// One set: three slots of up to MAX_GRID records, read in blocks of eight records that may reach past a
+// slot's last record (grid_total_pairs).  A context holds two sets (restore_other_set).
 int resident_slot_rows(const picp_ctx*) { return SLOTS * MAX_GRID + 8; }
+
+// The set of slots for the next launch of `grid` workgroups, clean, and the other set for that launch to
+// restore; only the first launch of a context (and the one after a failed HIP call) needs a fill kernel.
+static GridExchange take_slots(picp_ctx* ctx, int grid) {
+    GridExchange gx{ctx->rslots, nullptr, 0, ctx->resident_spin_limit};
+    if (grid <= 1) return gx; // a single workgroup exchanges nothing
+    const int n = resident_slot_rows(ctx) * RW;
+    const int set = ctx->slot_set;
+    gx.slots = ctx->rslots + (size_t)set * n;
+    gx.restore = ctx->rslots + (size_t)(1 - set) * n;
+    gx.restore_doubles = n;
+    if (!ctx->slots_clean[set])
+        hipLaunchKernelGGL(resident_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, gx.slots, n);
+    ctx->slots_clean[set] = 0;     // the launch dirties its own set ...
+    ctx->slots_clean[1 - set] = 1; // ... and leaves the other one clean, whether it completes or gives up
+    ctx->slot_set = 1 - set;
+    return gx;
+}
 
 int64_t resident_capacity(const picp_ctx* ctx) {
     const int64_t cap = (int64_t)resident_grid(ctx) * NTR * R_MAX;
@@ -897,7 +932,7 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
                             const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
                             hipEvent_t e1) {
     const CameraK c = camera_of(cam);
-    GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
+    const GridExchange gx = take_slots(ctx, grid);
     // The lean form where it pays (up to R_LEAN_MAX correspondences per thread), unless a recent loop met
     // immoderate values or the camera matrix itself is not moderate.
     bool lean = (R <= R_LEAN_MAX) && ctx->full_select_calls == 0;
@@ -921,23 +956,6 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
     else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, u, v, x, y, z, M, state, pose, c, *sched,
                            gx, hist, hist_rows, host_state);
-}
-
-static void fill_slots(picp_ctx* ctx, int grid) {
-    const int n = SLOTS * grid * RW;
-    hipLaunchKernelGGL(resident_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->rslots, n);
-}
-
-// Behind a single-launch loop: restores the exchange slots for the next loop of up to the same
-// number of workgroups.  Only enqueued (stream order puts it after the loop and before whatever the
-// caller enqueues next); the host waits for an event recorded in front of it, not for this kernel.
-void resident_refill(picp_ctx* ctx) {
-    if (ctx->resident_last_grid > 1) {
-        fill_slots(ctx, ctx->resident_last_grid);
-        ctx->resident_clean_grid = ctx->resident_last_grid;
-    } else {
-        ctx->resident_clean_grid = 1; // a single workgroup exchanges nothing
-    }
 }
 
 // Enqueues the loop, starting from w_T_c0_host.  Precondition:
@@ -967,9 +985,6 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     if (host_state != nullptr) host_state[ST_STOP] = 0.0;
     StartPose pose;
     memcpy(pose.m, w_T_c0_host, sizeof(pose.m));
-    if (ctx->resident_clean_grid < grid) fill_slots(ctx, grid); // else a previous call left them clean
-    ctx->resident_clean_grid = 0;                               // the loop dirties them
-    ctx->resident_last_grid = grid;
 #define PICP_RESIDENT_CASE(RR) \
     case RR: launch_resident<RR>(ctx, grid, u, v, x, y, z, M, state, pose, cam, sched, hist, hist_rows, host_state, e0, e1); break;
     switch (R) {
@@ -1003,11 +1018,8 @@ int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const do
     if (host_state != nullptr) host_state[ST_STOP] = 0.0;
     StartPose pose;
     memcpy(pose.m, w_T_c0_host, sizeof(pose.m));
-    if (ctx->resident_clean_grid < grid) fill_slots(ctx, grid);
-    ctx->resident_clean_grid = 0;
-    ctx->resident_last_grid = grid;
     const CameraK c = camera_of(cam);
-    GridExchange gx{ctx->rslots, ctx->resident_spin_limit};
+    const GridExchange gx = take_slots(ctx, grid);
     PeerExchange px;
     memset(&px, 0, sizeof(px));
     px.world = 1;
