@@ -422,10 +422,9 @@ static void result_from_state(const double* h, const double* w_T_c0_host, picp_r
     result->best_error = h[ST_BEST_ERR];
 }
 
-// Waits for a single-launch loop that has just been enqueued (for an event behind it, not for the
-// stream).
+// Waits for a single-launch loop that has just been enqueued with ctx->loop_done as its completion
+// event (bound to the dispatch: an event recorded behind it would be a packet of its own on the stream).
 static int wait_for_loop(picp_ctx* ctx) {
-    PICP_HIP_CHECK(hipEventRecord(ctx->loop_done, ctx->stream));
     PICP_HIP_CHECK(hipEventSynchronize(ctx->loop_done)); // (polling hipEventQuery instead measured slower)
     return PICP_OK;
 }
@@ -778,7 +777,7 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
     // Inputs that fit the register files run the whole loop in one launch (picp_resident.hip).
     if (single_launch && M > 0 && M <= resident_capacity(ctx) && sched->num_iterations > 0) {
         if (int rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
-                                      ctx->pinned, nullptr, nullptr))
+                                      ctx->pinned, nullptr, ctx->loop_done))
             return rc;
         if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
         if (ctx->pinned[ST_STOP] == STOP_IMMODERATE) {
@@ -786,7 +785,7 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
             // run the form without that assumption, now and for the next calls (such inputs come in runs).
             immoderate_exit(ctx);
             if (int rc = enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
-                                          ctx->pinned, nullptr, nullptr))
+                                          ctx->pinned, nullptr, ctx->loop_done))
                 return rc;
             if (int rc = wait_for_loop(ctx)) return rc;
         }
@@ -802,7 +801,7 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
     if (single_launch && M > resident_capacity(ctx) && ctx->resident_limit > 0 && M <= ctx->persistent_limit &&
         sched->num_iterations > 0 && aligned16(u) && aligned16(v) && aligned16(x) && aligned16(y) && aligned16(z)) {
         if (int rc = enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
-                                        ctx->pinned, nullptr, nullptr))
+                                        ctx->pinned, nullptr, ctx->loop_done))
             return rc;
         if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
         if (ctx->pinned[ST_STOP] != 0.0) {
@@ -863,14 +862,13 @@ int picp_run_sharded(picp_ctx* ctx, const double* u, const double* v, const doub
         PICP_HIP_CHECK(hipEventCreate(&ctx->prof0));
         PICP_HIP_CHECK(hipEventCreate(&ctx->prof1));
     }
-    hipEvent_t e0 = ctx->time_launches ? ctx->prof0 : nullptr, e1 = ctx->time_launches ? ctx->prof1 : nullptr;
+    hipEvent_t e0 = ctx->time_launches ? ctx->prof0 : nullptr, e1 = ctx->time_launches ? ctx->prof1 : ctx->loop_done;
     if (int rc = enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
                                     ctx->pinned, e0, e1, true))
         return rc;
-    if (int rc = wait_for_loop(ctx)) return rc; // the kernel left the final state in ctx->pinned
+    PICP_HIP_CHECK(hipEventSynchronize(e1)); // the kernel left the final state in ctx->pinned
     if (e0 != nullptr) {
         float ms = 0.f;
-        PICP_HIP_CHECK(hipEventSynchronize(e1));
         PICP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
         ctx->last_launch_ms = ms;
     }
@@ -916,12 +914,10 @@ int picp_run_enqueue(picp_ctx* ctx, const double* u, const double* v, const doub
     DeviceGuard g(ctx->device);
     double* host_state = ctx->pinned + PINNED_SLOT0 + (size_t)slot * PINNED_SLOT_STRIDE;
     const int rc = on_chip ? enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
-                                              host_state, nullptr, nullptr)
+                                              host_state, nullptr, ctx->slot_done[slot])
                            : enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist,
-                                                (int)hist_rows, host_state, nullptr, nullptr);
-    if (rc != PICP_OK) return rc;
-    PICP_HIP_CHECK(hipEventRecord(ctx->slot_done[slot], ctx->stream));
-    return PICP_OK;
+                                                (int)hist_rows, host_state, nullptr, ctx->slot_done[slot]);
+    return rc; // (the slot's event is the dispatch's completion event: no packet of its own behind the loop)
 }
 
 int picp_run_collect(picp_ctx* ctx, int32_t slot, const double* w_T_c0_host, picp_result* result) {

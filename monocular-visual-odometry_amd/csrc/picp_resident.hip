@@ -950,7 +950,7 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
             if (ctx->device < MAX_DEVICES) raised[which][ctx->device] = true;
         }
     }
-    if (e0 != nullptr)
+    if (e0 != nullptr || e1 != nullptr) // events bound to this dispatch: no marker packet of their own on the stream
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, pose, c,
                               *sched, gx, hist, hist_rows, host_state);
     else
@@ -1038,7 +1038,7 @@ int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const do
     if (sharded)
         kern = rev ? (pin ? icp_persistent_kernel<true, true, true> : icp_persistent_kernel<false, true, true>)
                    : (pin ? icp_persistent_kernel<true, false, true> : icp_persistent_kernel<false, false, true>);
-    if (e0 != nullptr)
+    if (e0 != nullptr || e1 != nullptr) // events bound to this dispatch: no marker packet of their own on the stream
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), 0, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, pose, c,
                               *sched, gx, hist, hist_rows, host_state, px);
     else
