@@ -536,8 +536,9 @@ def bench_assoc(args):
     dt = timing["hash"]                                           # what picp_associate runs at this size
     sqs, sqs_src = committed_counters("r*_pmc_sq_assoc*.json", "assoc_scan_kernel")
     scan_valu = valu_block(sqs, sqs_src, timing["scan"] * 1e3)
-    # the join reads both descriptor sets once and writes / probes an 8-byte-per-slot table of 2 n slots (rounded
-    # up to a power of two) and the two index lists
+    # the join reads both descriptor sets once and writes / probes an 8-byte-per-slot table, priced at 2 n slots
+    # rounded up to a power of two (the library spreads it over 4 n: shorter probe sequences for more bytes, which
+    # are its own affair), and writes the two index lists
     table_bytes = 8.0 * (1 << int(np.ceil(np.log2(2 * n))))
     join_bytes = 2 * n * D * 8.0 + 2 * table_bytes + 2 * n * 8.0
     out = {"metric": "appearance-association pair evaluations/sec (N1 x N2 per call: the pairs the reference's double "
@@ -549,13 +550,13 @@ def bench_assoc(args):
                                   "exactly one exact match, projection = 0", "method": "hash join (picp_associate's "
                                   "choice at this size; identical pair list to the all-pairs scan)",
                       "all_pairs_scan_ms": timing["scan"] * 1e3, "all_pairs_scan_pair_evaluations_per_s": pairs / timing["scan"]},
-           "roofline": {"bound": "hbm", "kernel": "hash_build_kernel + hash_count_kernel + emit (hash join)",
+           "roofline": {"bound": "hbm", "kernel": "hash_place_kernel + hash_settle_kernel + hash_count_kernel + offsets + hash_emit_kernel (hash join)",
                         "achieved": join_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": join_bytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "bytes_per_call": join_bytes,
                         "note": "algorithmic bytes of the join: both descriptor sets once, the table written and probed "
-                                "once, two index lists; time = whole picp_associate call (several launches and one "
-                                "count read-back), not one kernel",
+                                "once, two index lists; time = whole picp_associate call (five launches and one "
+                                "wait), not one kernel",
                         "all_pairs_scan": {"bound": "int_valu", "valu": scan_valu,
                                            "instructions_per_pair": (scan_valu["valu_wave_instructions_per_launch"] * 64 / pairs)
                                            if scan_valu else 1.5,

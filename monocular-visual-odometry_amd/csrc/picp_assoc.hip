@@ -119,7 +119,7 @@ __global__ __launch_bounds__(ANT) void assoc_scan_kernel(const double* __restric
 
 // ---- hash join: the same pairs without the all-pairs scan --------------------------------------
 // Equal rows have equal hashes, so each query row only needs the rows of set 2 in its hash bucket.
-// Set 2 goes into an open-addressing table (linear probing, at most half full); an entry is
+// Set 2 goes into an open-addressing table (linear probing, at most a quarter full); an entry is
 // (32-bit tag of the hash) << 32 | (row + 1), 0 = empty.  A query walks its probe sequence to the
 // first empty entry and runs the full comparison (rows_equal) on every entry whose tag matches, so
 // the set of pairs is exactly that of the all-pairs scan; within a query row the matches are
@@ -147,7 +147,7 @@ __device__ __forceinline__ bool row_hash(const double* __restrict__ row, int D, 
     }
     h *= 0xbf58476d1ce4e5b9ull;
     h ^= h >> 32;
-    *h_out = h;
+    *h_out = h ? h : 1ull; // 0 is kept free: it marks a row without a hash in hash_place_kernel's output
     return ok;
 }
 
@@ -160,23 +160,62 @@ __device__ __forceinline__ void stage_rows(const double* __restrict__ app, int64
                                            double* lds) {
     const double* src = app + row0 * D;
     const int n = rows * D;
-    int r = threadIdx.x / D, c = threadIdx.x % D;
-    const int dr = ANT / D, dc = ANT % D;
-    for (int e = threadIdx.x; e < n; e += ANT) {
-        lds[r * DS + c] = src[e];
-        r += dr;
-        c += dc;
-        if (c >= D) {
-            c -= D;
-            r += 1;
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        // 16-byte loads, two consecutive words each (the second may belong to the next row)
+        const double2* src2 = reinterpret_cast<const double2*>(src);
+        const int step = 2 * ANT;
+        int r = (2 * (int)threadIdx.x) / D, c = (2 * (int)threadIdx.x) % D;
+        const int dr = step / D, dc = step % D;
+        for (int e = 2 * threadIdx.x; e + 1 < n; e += step) {
+            const double2 v = src2[e >> 1];
+            lds[r * DS + c] = v.x;
+            lds[(c + 1 < D) ? r * DS + c + 1 : (r + 1) * DS] = v.y;
+            r += dr;
+            c += dc;
+            if (c >= D) {
+                c -= D;
+                r += 1;
+            }
+        }
+        if ((n & 1) && threadIdx.x == 0) lds[(rows - 1) * DS + D - 1] = src[n - 1];
+    } else {
+        int r = threadIdx.x / D, c = threadIdx.x % D;
+        const int dr = ANT / D, dc = ANT % D;
+        for (int e = threadIdx.x; e < n; e += ANT) {
+            lds[r * DS + c] = src[e];
+            r += dr;
+            c += dc;
+            if (c >= D) {
+                c -= D;
+                r += 1;
+            }
         }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(ANT) void hash_build_kernel(const double* __restrict__ app2, int64_t N2, int D,
+// Clears the table (and the flag word behind it).  A kernel of the library's own rather than
+// hipMemsetAsync: that call keeps the host busy for longer than the clearing takes on the device, and
+// the device then waits for the launches behind it.  words is a multiple of 2; table is 16-byte aligned.
+__global__ __launch_bounds__(ANT) void hash_clear_kernel(unsigned long long* __restrict__ table, int64_t words) {
+    ulonglong2* t2 = reinterpret_cast<ulonglong2*>(table);
+    const int64_t n2 = words / 2;
+    for (int64_t k = (int64_t)blockIdx.x * ANT + threadIdx.x; k < n2; k += (int64_t)gridDim.x * ANT)
+        t2[k] = ulonglong2{0ull, 0ull};
+}
+
+// The table is built in two launches, because atomic operations are what a one-launch build spends
+// its time in (three quarters of it at 10^6 rows): compare-and-swap on a random entry costs several
+// times a store to it.
+// First launch: every row of set 2 writes its entry into its home slot with a plain 8-byte store --
+// of the rows that share a home slot one survives, whichever store lands last -- and saves its hash.
+// Second launch: a row finds its own entry in its home slot (nine rows in ten at a quarter load) or goes
+// down the probe sequence with compare-and-swap from the next slot on.  The home slot is occupied
+// either way, so a query's walk from the home slot to the first empty entry still meets every row
+// with that hash.
+__global__ __launch_bounds__(ANT) void hash_place_kernel(const double* __restrict__ app2, int64_t N2, int D,
                                                          unsigned long long* __restrict__ table, uint64_t mask,
-                                                         int* __restrict__ flag) {
+                                                         uint64_t* __restrict__ hashes) {
     extern __shared__ double rows_lds[];
     const int DS = D | 1;
     const int64_t row0 = (int64_t)blockIdx.x * ANT;
@@ -185,14 +224,42 @@ __global__ __launch_bounds__(ANT) void hash_build_kernel(const double* __restric
     const int64_t j = row0 + threadIdx.x;
     if (j >= N2) return;
     uint64_t h;
-    if (!row_hash(rows_lds + threadIdx.x * DS, D, &h)) return;
+    if (!row_hash(rows_lds + threadIdx.x * DS, D, &h)) {
+        hashes[j] = 0; // a row with a NaN equals nothing: it stays out of the table
+        return;
+    }
+    hashes[j] = h;
+    table[h & mask] = ((h >> 32) << 32) | (unsigned long long)(j + 1);
+}
+
+__global__ __launch_bounds__(ANT) void hash_settle_kernel(const uint64_t* __restrict__ hashes, int64_t N2,
+                                                          unsigned long long* __restrict__ table, uint64_t mask,
+                                                          int* __restrict__ flag, int* __restrict__ host_flag) {
+    const int64_t j = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    if (j >= N2) return;
+    const uint64_t h = hashes[j];
+    if (h == 0) return;
     const unsigned long long entry = ((h >> 32) << 32) | (unsigned long long)(j + 1);
     uint64_t slot = h & mask;
-    for (int probe = 0; probe < HASH_MAX_PROBE; ++probe) {
-        if (atomicCAS(&table[slot], 0ull, entry) == 0ull) return;
-        slot = (slot + 1) & mask;
+    if (table[slot] == entry) return;
+    // Look before swapping: the next HASH_LOOK entries are read together, and the swap is tried on the first
+    // empty one only (an entry seen occupied stays occupied; one seen empty may have been taken since, then
+    // the swap fails and the walk goes on behind it).
+    slot = (slot + 1) & mask;
+    for (int probe = 1; probe < HASH_MAX_PROBE;) {
+        unsigned long long e[HASH_LOOK];
+#pragma unroll
+        for (int k = 0; k < HASH_LOOK; ++k)
+            e[k] = __hip_atomic_load(&table[(slot + k) & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int k = 0;
+        while (k < HASH_LOOK && e[k] != 0ull) ++k;
+        if (k < HASH_LOOK && atomicCAS(&table[(slot + k) & mask], 0ull, entry) == 0ull) return;
+        const int passed = k < HASH_LOOK ? k + 1 : HASH_LOOK;
+        probe += passed;
+        slot = (slot + passed) & mask;
     }
     atomicExch(flag, 1);
+    *host_flag = 1;
 }
 
 // rows_equal for a query row held in LDS against a row of set 2 in memory.  WIDE: the rows of set 2
@@ -300,13 +367,36 @@ __device__ __forceinline__ bool verify_candidates(int64_t cand, const double* q_
     return equal;
 }
 
+__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* lds /*ANT/64 + 1*/, int64_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < ANT / 64; ++w) {
+        if (w < wave) base += lds[w];
+        tot += lds[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
 template <bool WIDE>
 __global__ __launch_bounds__(ANT) void hash_count_kernel(const double* __restrict__ app1, int64_t N1,
                                                          const double* __restrict__ app2, int D,
                                                          const unsigned long long* __restrict__ table, uint64_t mask,
-                                                         int64_t* __restrict__ count, int64_t* __restrict__ first,
-                                                         int* __restrict__ flag) {
+                                                         uint64_t* __restrict__ found,
+                                                         int64_t* __restrict__ blocksum, int* __restrict__ flag,
+                                                         int* __restrict__ host_flag) {
     extern __shared__ double rows_lds[];
+    __shared__ int64_t scan_lds[ANT / 64 + 1];
     const int DS = D | 1;
     const int64_t row0 = (int64_t)blockIdx.x * ANT;
     const int64_t left = N1 - row0;
@@ -324,7 +414,7 @@ __global__ __launch_bounds__(ANT) void hash_count_kernel(const double* __restric
     int probe = 0;
     bool complete = true;
     // A walk is a chain of dependent random reads, and the wave stays in it until its longest walk has
-    // ended (about ten entries at half load); HASH_LOOK entries are therefore fetched per step, all in
+    // ended (a handful of entries at a quarter load); HASH_LOOK entries are therefore fetched per step, all in
     // flight together (they mostly share a cache line), which cuts the chain to two or three steps.
     while (__ballot(walking) != 0ull) {
         unsigned long long e[HASH_LOOK];
@@ -359,32 +449,46 @@ __global__ __launch_bounds__(ANT) void hash_count_kernel(const double* __restric
             }
         }
     }
-    if (i >= N1) return;
-    if (!complete || cnt > HASH_MAX_DUP) atomicExch(flag, 1);
-    count[i] = cnt;
-    first[i] = fst;
+    if (i < N1) {
+        if (!complete || cnt > HASH_MAX_DUP) { // the host repeats the association with the all-pairs scan
+            atomicExch(flag, 1);
+            *host_flag = 1;
+        }
+        // one word per query row: number of equal rows (at most HASH_MAX_PROBE) and the first of them
+        found[i] = ((uint64_t)cnt << 32) | (uint64_t)(uint32_t)fst;
+    } else {
+        cnt = 0;
+    }
+    // the workgroup's number of pairs, for the prefix sum over workgroups (scan_block_offsets_kernel);
+    // the emit kernel redoes the sum inside the workgroup from found[]
+    int64_t total;
+    (void)block_exclusive_scan(cnt, scan_lds, &total);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
 }
 
 __global__ __launch_bounds__(ANT) void hash_emit_kernel(const double* __restrict__ app1, int64_t N1,
                                                         const double* __restrict__ app2, int D,
                                                         const unsigned long long* __restrict__ table, uint64_t mask,
-                                                        const int64_t* __restrict__ count,
-                                                        const int64_t* __restrict__ first,
-                                                        const int64_t* __restrict__ offset, int64_t* __restrict__ idx1,
+                                                        const uint64_t* __restrict__ found,
+                                                        const int64_t* __restrict__ blockstart, int64_t* __restrict__ idx1,
                                                         int64_t* __restrict__ idx2, int64_t capacity,
                                                         const int* __restrict__ flag) {
-    const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
-    if (i >= N1) return;
+    __shared__ int64_t scan_lds[ANT / 64 + 1];
     // The count kernel gave up (long walks or very many equal rows): the host repeats the association with
     // the all-pairs scan, and the counts here may be huge or incomplete -- emit nothing.
     if (*flag != 0) return;
-    const int64_t c = count[i];
+    const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
+    const uint64_t f = (i < N1) ? found[i] : 0ull;
+    const int64_t c = (int64_t)(f >> 32);
+    // this row's place in the output: the pairs of the workgroups before this one (blockstart), then those
+    // of the rows before it in the workgroup
+    int64_t total;
+    const int64_t o = blockstart[blockIdx.x] + block_exclusive_scan(c, scan_lds, &total);
     if (c == 0) return;
-    const int64_t o = offset[i];
     if (c == 1) {
         if (o < capacity) {
             idx1[o] = i;
-            idx2[o] = first[i];
+            idx2[o] = (int64_t)(f & 0xffffffffull);
         }
         return;
     }
@@ -407,27 +511,6 @@ __global__ __launch_bounds__(ANT) void hash_emit_kernel(const double* __restrict
 }
 
 // ---- exclusive prefix sum of int64 counts ------------------------------------------------------
-__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* lds /*ANT/64 + 1*/, int64_t* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int64_t t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) lds[wave] = inc;
-    __syncthreads();
-    int64_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < ANT / 64; ++w) {
-        if (w < wave) base += lds[w];
-        tot += lds[w];
-    }
-    __syncthreads();
-    *total = tot;
-    return base + inc - v;
-}
-
 __global__ __launch_bounds__(ANT) void scan_block_sums_kernel(const int64_t* __restrict__ count, int64_t N,
                                                               int64_t* __restrict__ blocksum) {
     __shared__ int64_t lds[ANT / 64 + 1];
@@ -441,19 +524,44 @@ __global__ __launch_bounds__(ANT) void scan_block_sums_kernel(const int64_t* __r
     if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
 
-// One workgroup turns blocksum[0..nb) into its exclusive scan and stores the grand total at [nb].
-__global__ __launch_bounds__(ANT) void scan_block_offsets_kernel(int64_t* __restrict__ blocksum, int64_t nb) {
-    __shared__ int64_t lds[ANT / 64 + 1];
-    int64_t carry = 0;
-    for (int64_t c0 = 0; c0 < nb; c0 += ANT) {
-        const int64_t i = c0 + threadIdx.x;
-        const int64_t v = (i < nb) ? blocksum[i] : 0;
-        int64_t tot;
-        const int64_t ex = block_exclusive_scan(v, lds, &tot);
-        if (i < nb) blocksum[i] = carry + ex;
-        carry += tot;
+// One workgroup of 1024 threads turns blocksum[0..nb) into its exclusive scan and stores the grand
+// total at [nb]: thread k takes a run of consecutive entries, the runs' sums are scanned across the
+// workgroup, and every thread then writes its run.  host_total: optional host-visible word that
+// receives the grand total as well.
+constexpr int OFFT = 1024;
+__global__ __launch_bounds__(OFFT) void scan_block_offsets_kernel(int64_t* __restrict__ blocksum, int64_t nb,
+                                                                  int64_t* __restrict__ host_total) {
+    __shared__ int64_t wave_sum[OFFT / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per = (nb + OFFT - 1) / OFFT;
+    const int64_t lo = (int64_t)threadIdx.x * per;
+    const int64_t hi = lo + per < nb ? lo + per : nb;
+    int64_t run = 0;
+    for (int64_t k = lo; k < hi; ++k) run += blocksum[k];
+    int64_t inc = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
     }
-    if (threadIdx.x == 0) blocksum[nb] = carry;
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    int64_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < OFFT / 64; ++w) {
+        if (w < wave) base += wave_sum[w];
+        total += wave_sum[w];
+    }
+    int64_t ex = base + inc - run;
+    for (int64_t k = lo; k < hi; ++k) {
+        const int64_t v = blocksum[k];
+        blocksum[k] = ex;
+        ex += v;
+    }
+    if (threadIdx.x == 0) {
+        blocksum[nb] = total;
+        if (host_total != nullptr) *host_total = total;
+    }
 }
 
 __global__ __launch_bounds__(ANT) void scan_write_kernel(const int64_t* __restrict__ count, int64_t N,
@@ -550,7 +658,7 @@ static int ensure_assoc_workspace(picp_ctx* ctx, int64_t N1, int64_t N2) {
         ctx->assoc_count = ctx->assoc_first = ctx->assoc_offset = ctx->assoc_blocksum = nullptr;
         ctx->assoc_cap = 0;
         const int64_t cap = N1 + N1 / 4 + 1024;
-        const int64_t nb = (cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        const int64_t nb = (cap + ANT - 1) / ANT; // one number per workgroup of the hash join's count kernel
         PICP_HIP_CHECK(hipMalloc(&ctx->assoc_count, sizeof(int64_t) * cap));
         PICP_HIP_CHECK(hipMalloc(&ctx->assoc_first, sizeof(int64_t) * cap));
         PICP_HIP_CHECK(hipMalloc(&ctx->assoc_offset, sizeof(int64_t) * (cap + 1)));
@@ -568,13 +676,24 @@ static int ensure_assoc_workspace(picp_ctx* ctx, int64_t N1, int64_t N2) {
     return PICP_OK;
 }
 
-static int ensure_hash_table(picp_ctx* ctx, int64_t entries) {
-    if (entries > ctx->assoc_table_cap) {
+// words: table entries plus the control words behind them; rows2: rows of set 2 (one saved hash each).
+static int ensure_hash_table(picp_ctx* ctx, int64_t words, int64_t rows2) {
+    if (words > ctx->assoc_table_cap) {
         if (ctx->assoc_table) (void)hipFree(ctx->assoc_table);
         ctx->assoc_table = nullptr;
         ctx->assoc_table_cap = 0;
-        PICP_HIP_CHECK(hipMalloc(&ctx->assoc_table, sizeof(unsigned long long) * (entries + 1))); // + the flag word
-        ctx->assoc_table_cap = entries;
+        const int64_t cap = words + words / 8;
+        PICP_HIP_CHECK(hipMalloc(&ctx->assoc_table, sizeof(unsigned long long) * cap));
+        ctx->assoc_table_cap = cap;
+        ctx->assoc_table_clean = 0;
+    }
+    if (rows2 > ctx->assoc_hash_cap) {
+        if (ctx->assoc_hash) (void)hipFree(ctx->assoc_hash);
+        ctx->assoc_hash = nullptr;
+        ctx->assoc_hash_cap = 0;
+        const int64_t cap = rows2 + rows2 / 4 + 1024;
+        PICP_HIP_CHECK(hipMalloc(&ctx->assoc_hash, sizeof(uint64_t) * cap));
+        ctx->assoc_hash_cap = cap;
     }
     return PICP_OK;
 }
@@ -593,74 +712,108 @@ int picp_set_association_mode(picp_ctx* ctx, int32_t mode) {
     return PICP_OK;
 }
 
-// One pass of the association with the chosen method.  *retry is set when the hash join met more
-// equal rows than it handles and the caller should run the all-pairs scan instead.
-static int associate_pass(picp_ctx* ctx, bool hashed, const double* app1, int64_t N1, const double* app2, int64_t N2,
-                          int D, int64_t* idx1, int64_t* idx2, int64_t capacity, int64_t* count, bool* retry) {
+// The hash join: table build (two launches), count, prefix sum over the workgroups' numbers of pairs,
+// emit; then one wait for the number of pairs and the fallback flag, which the kernels leave in
+// host-visible memory.  *retry is set when the join met more equal rows than it handles and the
+// caller should run the all-pairs scan.
+static int hash_join_pass(picp_ctx* ctx, const double* app1, int64_t N1, const double* app2, int64_t N2, int D,
+                          int64_t* idx1, int64_t* idx2, int64_t capacity, int64_t* count, bool* retry) {
     hipStream_t s = ctx->stream;
     *retry = false;
-    uint64_t mask = 0;
-    int* flag = nullptr;
-    const unsigned grid1 = (unsigned)((N1 + ANT - 1) / ANT);
-    if (hashed) {
-        uint64_t entries = 1024;
-        while (entries < 2 * (uint64_t)N2) entries <<= 1;
-        if (int rc = ensure_hash_table(ctx, (int64_t)entries)) return rc;
-        mask = entries - 1;
-        flag = reinterpret_cast<int*>(ctx->assoc_table + entries);
-        PICP_HIP_CHECK(hipMemsetAsync(ctx->assoc_table, 0, sizeof(unsigned long long) * (entries + 1), s));
-        const unsigned stage_bytes = (unsigned)(sizeof(double) * ANT * (size_t)(D | 1)); // the workgroup's rows in LDS
-        hipLaunchKernelGGL(hash_build_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), stage_bytes, s, app2, N2,
-                           D, ctx->assoc_table, mask, flag);
-        const bool wide = (D % 2 == 0) && ((reinterpret_cast<uintptr_t>(app2) & 15u) == 0);
-        auto count_kernel = wide ? hash_count_kernel<true> : hash_count_kernel<false>;
-        hipLaunchKernelGGL(count_kernel, dim3(grid1), dim3(ANT), stage_bytes, s, app1, N1, app2, D,
-                           (const unsigned long long*)ctx->assoc_table, mask, ctx->assoc_count, ctx->assoc_first, flag);
-    } else {
-        hipLaunchKernelGGL(assoc_keys_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, D,
-                           ctx->assoc_key);
-        // Few query rows: one per lane keeps more workgroups busy; many: eight per lane amortise
-        // the key fetches and the loop overhead.
-        int rows_per_lane = (N1 >= (int64_t)ANT * 8 * ctx->num_cus) ? 8 : 1;
-        if (const char* e = getenv("PICP_ASSOC_ROWS_PER_LANE")) rows_per_lane = atoi(e); // tuning override
-        const int R = rows_per_lane == 8 ? 8 : (rows_per_lane == 4 ? 4 : 1);
-        const unsigned nb = (unsigned)((N1 + (int64_t)ANT * R - 1) / ((int64_t)ANT * R));
-        auto kern = R == 8 ? assoc_scan_kernel<8> : (R == 4 ? assoc_scan_kernel<4> : assoc_scan_kernel<1>);
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(ANT), 0, s, app1, N1, app2, N2, D, (const uint32_t*)ctx->assoc_key,
-                           ctx->assoc_count, ctx->assoc_first);
+    const unsigned grid1 = (unsigned)((N1 + ANT - 1) / ANT), grid2 = (unsigned)((N2 + ANT - 1) / ANT);
+    uint64_t entries = 1024;
+    while (entries < 4 * (uint64_t)N2) entries <<= 1; // at most a quarter full
+
+    if (int rc = ensure_hash_table(ctx, (int64_t)entries + 2, N2)) return rc; // + the flag word, and one to keep the count even
+    const uint64_t mask = entries - 1;
+    int* flag = reinterpret_cast<int*>(ctx->assoc_table + entries);
+    int64_t* h = reinterpret_cast<int64_t*>(ctx->pinned);
+    h[0] = 0;
+    h[1] = 0;
+    int* host_flag = reinterpret_cast<int*>(h + 1);
+    // The table is cleared behind the join that used it, after the point the host waits for, so the next join
+    // finds it clean and the clearing runs while the host turns around; only a first or larger table is
+    // cleared here.
+    if (ctx->assoc_table_clean < (int64_t)entries + 2)
+        hipLaunchKernelGGL(hash_clear_kernel, dim3((unsigned)(8 * ctx->num_cus)), dim3(ANT), 0, s, ctx->assoc_table,
+                           (int64_t)entries + 2);
+    ctx->assoc_table_clean = 0;
+    const unsigned stage_bytes = (unsigned)(sizeof(double) * ANT * (size_t)(D | 1)); // the workgroup's rows in LDS
+    hipLaunchKernelGGL(hash_place_kernel, dim3(grid2), dim3(ANT), stage_bytes, s, app2, N2, D, ctx->assoc_table, mask,
+                       ctx->assoc_hash);
+    hipLaunchKernelGGL(hash_settle_kernel, dim3(grid2), dim3(ANT), 0, s, (const uint64_t*)ctx->assoc_hash, N2,
+                       ctx->assoc_table, mask, flag, host_flag);
+    const bool wide = (D % 2 == 0) && ((reinterpret_cast<uintptr_t>(app2) & 15u) == 0);
+    auto count_kernel = wide ? hash_count_kernel<true> : hash_count_kernel<false>;
+    hipLaunchKernelGGL(count_kernel, dim3(grid1), dim3(ANT), stage_bytes, s, app1, N1, app2, D,
+                       (const unsigned long long*)ctx->assoc_table, mask, reinterpret_cast<uint64_t*>(ctx->assoc_count),
+                       ctx->assoc_blocksum, flag, host_flag);
+    hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(OFFT), 0, s, ctx->assoc_blocksum, (int64_t)grid1, h);
+    PICP_HIP_CHECK(hipGetLastError());
+    // The pairs are emitted before the host knows their number: the emit kernel writes nothing beyond
+    // `capacity`, so one wait at the end serves the count, the fallback flag and the index lists (a second
+    // wait between counting and emitting costs more than an emit whose output is then thrown away).
+    if (capacity > 0) {
+        hipLaunchKernelGGL(hash_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, D,
+                           (const unsigned long long*)ctx->assoc_table, mask,
+                           reinterpret_cast<const uint64_t*>(ctx->assoc_count), (const int64_t*)ctx->assoc_blocksum, idx1,
+                           idx2, capacity, (const int*)flag);
+        PICP_HIP_CHECK(hipGetLastError());
     }
+    PICP_HIP_CHECK(hipEventRecord(ctx->assoc_done, s));
+    hipLaunchKernelGGL(hash_clear_kernel, dim3((unsigned)(8 * ctx->num_cus)), dim3(ANT), 0, s, ctx->assoc_table,
+                       (int64_t)entries + 2);
+    PICP_HIP_CHECK(hipGetLastError());
+    ctx->assoc_table_clean = (int64_t)entries + 2;
+    PICP_HIP_CHECK(hipEventSynchronize(ctx->assoc_done));
+    if (h[1] != 0) {
+        *retry = true;
+        return PICP_OK;
+    }
+    *count = h[0];
+    if (h[0] > capacity) {
+        set_error("picp_associate: %lld pairs found, index arrays hold %lld", (long long)h[0], (long long)capacity);
+        return PICP_ERR_CAPACITY;
+    }
+    return PICP_OK;
+}
+
+// The all-pairs scan: counts, prefix sum, emit.
+static int scan_pass(picp_ctx* ctx, const double* app1, int64_t N1, const double* app2, int64_t N2, int D,
+                     int64_t* idx1, int64_t* idx2, int64_t capacity, int64_t* count) {
+    hipStream_t s = ctx->stream;
+    const unsigned grid1 = (unsigned)((N1 + ANT - 1) / ANT);
+    hipLaunchKernelGGL(assoc_keys_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, D,
+                       ctx->assoc_key);
+    // Few query rows: one per lane keeps more workgroups busy; many: eight per lane amortise
+    // the key fetches and the loop overhead.
+    int rows_per_lane = (N1 >= (int64_t)ANT * 8 * ctx->num_cus) ? 8 : 1;
+    if (const char* e = getenv("PICP_ASSOC_ROWS_PER_LANE")) rows_per_lane = atoi(e); // tuning override
+    const int R = rows_per_lane == 8 ? 8 : (rows_per_lane == 4 ? 4 : 1);
+    const unsigned nbs = (unsigned)((N1 + (int64_t)ANT * R - 1) / ((int64_t)ANT * R));
+    auto kern = R == 8 ? assoc_scan_kernel<8> : (R == 4 ? assoc_scan_kernel<4> : assoc_scan_kernel<1>);
+    hipLaunchKernelGGL(kern, dim3(nbs), dim3(ANT), 0, s, app1, N1, app2, N2, D, (const uint32_t*)ctx->assoc_key,
+                       ctx->assoc_count, ctx->assoc_first);
     PICP_HIP_CHECK(hipGetLastError());
     const int64_t nb = (N1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count,
                        N1, ctx->assoc_blocksum);
-    hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(ANT), 0, s, ctx->assoc_blocksum, nb);
+    hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(OFFT), 0, s, ctx->assoc_blocksum, nb, (int64_t*)nullptr);
     hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count, N1,
                        (const int64_t*)ctx->assoc_blocksum, nb, ctx->assoc_offset);
     PICP_HIP_CHECK(hipGetLastError());
-    // The pairs are emitted before the host knows their number: the emit kernels write nothing beyond
-    // `capacity`, so one wait at the end serves the count, the fallback flag and the index lists (a second
-    // wait between counting and emitting costs more than an emit whose output is then thrown away).
+    // The pairs are emitted before the host knows their number: the emit kernel writes nothing beyond
+    // `capacity`, so one wait at the end serves the count and the index lists (a second wait between
+    // counting and emitting costs more than an emit whose output is then thrown away).
     if (capacity > 0) {
-        if (hashed)
-            hipLaunchKernelGGL(hash_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, D,
-                               (const unsigned long long*)ctx->assoc_table, mask, (const int64_t*)ctx->assoc_count,
-                               (const int64_t*)ctx->assoc_first, (const int64_t*)ctx->assoc_offset, idx1, idx2,
-                               capacity, (const int*)flag);
-        else
-            hipLaunchKernelGGL(assoc_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, N2, D,
-                               (const int64_t*)ctx->assoc_count, (const int64_t*)ctx->assoc_first,
-                               (const int64_t*)ctx->assoc_offset, idx1, idx2, capacity);
+        hipLaunchKernelGGL(assoc_emit_kernel, dim3(grid1), dim3(ANT), 0, s, app1, N1, app2, N2, D,
+                           (const int64_t*)ctx->assoc_count, (const int64_t*)ctx->assoc_first,
+                           (const int64_t*)ctx->assoc_offset, idx1, idx2, capacity);
         PICP_HIP_CHECK(hipGetLastError());
     }
     int64_t* h = reinterpret_cast<int64_t*>(ctx->pinned);
-    h[1] = 0;
     PICP_HIP_CHECK(hipMemcpyAsync(h, ctx->assoc_offset + N1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    if (hashed) PICP_HIP_CHECK(hipMemcpyAsync(h + 1, flag, sizeof(int), hipMemcpyDeviceToHost, s));
     PICP_HIP_CHECK(hipStreamSynchronize(s));
-    if (hashed && h[1] != 0) {
-        *retry = true;
-        return PICP_OK;
-    }
     *count = h[0];
     if (h[0] > capacity) {
         set_error("picp_associate: %lld pairs found, index arrays hold %lld", (long long)h[0], (long long)capacity);
@@ -688,12 +841,13 @@ int picp_associate(picp_ctx* ctx, const double* app1, int64_t N1, const double* 
     if (ctx->assoc_mode == 2 && !stageable) ctx->assoc_hash_fallbacks += 1; // wider descriptors: the scan has no limit
     const bool hashed = stageable && (ctx->assoc_mode == 2 ||
                                       (ctx->assoc_mode == 0 && fits && (double)N1 * (double)N2 >= 4.0e9));
-    bool retry = false;
-    if (int rc = associate_pass(ctx, hashed, app1, N1, app2, N2, (int)D, idx1, idx2, capacity, count, &retry)) return rc;
-    if (!retry) return PICP_OK;
-    // many equal rows: the all-pairs scan has no limit on them
-    ctx->assoc_hash_fallbacks += 1;
-    return associate_pass(ctx, false, app1, N1, app2, N2, (int)D, idx1, idx2, capacity, count, &retry);
+    if (hashed) {
+        bool retry = false;
+        if (int rc = hash_join_pass(ctx, app1, N1, app2, N2, (int)D, idx1, idx2, capacity, count, &retry)) return rc;
+        if (!retry) return PICP_OK;
+        ctx->assoc_hash_fallbacks += 1; // many equal rows: the all-pairs scan has no limit on them
+    }
+    return scan_pass(ctx, app1, N1, app2, N2, (int)D, idx1, idx2, capacity, count);
 }
 
 int picp_association_fallbacks(picp_ctx* ctx) { return ctx ? ctx->assoc_hash_fallbacks : 0; }

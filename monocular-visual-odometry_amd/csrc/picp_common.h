@@ -29,8 +29,12 @@ struct picp_ctx {
     uint32_t* assoc_key;   // [key_cap] low words of component 0 of set 2
     int64_t assoc_cap;
     int64_t assoc_key_cap;
-    unsigned long long* assoc_table; // [table_cap + 1] hash-join table and its fallback flag
+    unsigned long long* assoc_table; // [table_cap] hash-join table and the join's control words behind it
     int64_t assoc_table_cap;
+    int64_t assoc_table_clean; // leading words of the table known to be zero (cleared behind the last join)
+    hipEvent_t assoc_done;     // recorded behind a join's last kernel, before the table is cleared again
+    uint64_t* assoc_hash;  // [hash_cap] hashes of the rows of set 2, between the two launches of the table build
+    int64_t assoc_hash_cap;
     int assoc_mode;           // 0 auto, 1 all-pairs scan, 2 hash join
     int assoc_hash_fallbacks; // hash joins abandoned for the all-pairs scan (heavy duplication)
     double* pinned; // host-pinned staging for small read-backs

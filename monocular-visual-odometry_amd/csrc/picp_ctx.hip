@@ -72,6 +72,7 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     if (e == hipSuccess) e = hipMemset(ctx->arrive, 0, sizeof(unsigned) * 64);
     if (e == hipSuccess) e = hipMalloc(&ctx->rslots, sizeof(double) * 2 * PICP_S2_DOUBLES * resident_slot_rows(ctx));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->loop_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->assoc_done, hipEventDisableTiming);
     for (int k = 0; k < PICP_ASYNC_SLOTS && e == hipSuccess; ++k)
         e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
     ctx->resident_limit = INT64_MAX; // i.e. whatever fits (resident_capacity)
@@ -107,6 +108,7 @@ int picp_destroy(picp_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->rslots) (void)hipFree(ctx->rslots);
     if (ctx->loop_done) (void)hipEventDestroy(ctx->loop_done);
+    if (ctx->assoc_done) (void)hipEventDestroy(ctx->assoc_done);
     if (ctx->prof0) (void)hipEventDestroy(ctx->prof0);
     if (ctx->prof1) (void)hipEventDestroy(ctx->prof1);
     for (int k = 0; k < PICP_ASYNC_SLOTS; ++k)
@@ -117,6 +119,7 @@ int picp_destroy(picp_ctx* ctx) {
     if (ctx->assoc_blocksum) (void)hipFree(ctx->assoc_blocksum);
     if (ctx->assoc_key) (void)hipFree(ctx->assoc_key);
     if (ctx->assoc_table) (void)hipFree(ctx->assoc_table);
+    if (ctx->assoc_hash) (void)hipFree(ctx->assoc_hash);
     delete ctx;
     return PICP_OK;
 }
