@@ -19,6 +19,58 @@ from .two_view import find_essential_mat, recover_pose, triangulate_points
 from .geometry_utils import Rt2T
 
 
+def summary_lines(results, is_valid, lo, hi):
+    """The per-frame summary the reference prints (src/ProjectiveICP.py:122-138), line for line:
+    labels padded to a 38-character column, the error rounded to 5 places, the other means to
+    whole numbers, the best and worst iteration's values as they are."""
+    def row(label, value, tail=''):
+        return f'  - {label}:'.ljust(38) + f'{value}{tail}'
+    out = [row('Valid transformation', is_valid), row('Num iterations', len(results['T']), '\n')]
+    for title, key in (('Error', 'error'), ('Num inliers', 'num_inliers'),
+                       ('Kernel threshold', 'kernel_threshold'), ('Dumping factor', 'dumping_factor')):
+        vals = results[key]
+        if key == 'error':
+            out.append(row(f'{title} best iteration', np.round(vals[lo], 5), f' (index: {lo})'))
+            out.append(row(f'{title} worst iteration', np.round(vals[hi], 5), f' (index: {hi})'))
+            out.append(row(f'Mean {title.lower()}', np.round(np.mean(vals), 5), '\n'))
+        else:
+            out.append(row(f'{title} best iteration', vals[lo]))
+            out.append(row(f'{title} worst iteration', vals[hi]))
+            out.append(row(f'Mean {title.lower()}', np.round(np.mean(vals)), '\n'))
+    return out
+
+
+def results_from_history(hist, base_kernel_threshold, min_kernel_threshold, base_dumping_factor):
+    """Device history rows -> the reference's iterations_results dict (src/ProjectiveICP.py:173).
+
+    The reference's threshold and damping values are Python numbers whose type follows its
+    arithmetic: the threshold keeps the type it has under ``+= 10`` / ``-= 10`` and takes the type
+    of ``min_kernel_threshold`` when every pair is an inlier (:200-205); the damping factor stays
+    what the caller passed until the first ``/= 2`` or ``*= 2`` makes it a float for good
+    (:224-225).  Integer parameters (the YAML's) therefore give ``990`` and ``32.0``, not
+    ``990.0`` and ``32``; the lists here carry the same types."""
+    def is_int(x):
+        return isinstance(x, (int, np.integer)) and not isinstance(x, bool)
+    thr_int, min_int, damp_int = is_int(base_kernel_threshold), is_int(min_kernel_threshold), is_int(base_dumping_factor)
+    prev_damp = float(base_dumping_factor)
+    thresholds, dampings = [], []
+    for k in range(hist.shape[0]):
+        if hist[k, _lib.H_NUM_INLIERS] == hist[k, _lib.H_N_INSIDE]:      # :200-201
+            thr_int = min_int
+        t = float(hist[k, _lib.H_KERNEL_THR])
+        thresholds.append(int(t) if thr_int and t.is_integer() else t)
+        d = float(hist[k, _lib.H_DAMPING])
+        if d != prev_damp:
+            damp_int = False
+        prev_damp = d
+        dampings.append(int(d) if damp_int and d.is_integer() else d)
+    return {'T': [hist[k, _lib.H_T:_lib.H_T + 16].reshape(4, 4).copy() for k in range(hist.shape[0])],
+            'error': [float(e) for e in hist[:, _lib.H_ERROR]],
+            'num_inliers': [int(n) for n in hist[:, _lib.H_NUM_INLIERS]],
+            'kernel_threshold': thresholds,
+            'dumping_factor': dampings}
+
+
 class ProjectiveICP:
     def __init__(self, camera,
                  data,
@@ -128,14 +180,8 @@ class ProjectiveICP:
         print(f'Transformation of frame {frame_index}: w_T_c{frame_index} - previous pose')
         print(f'Relative transformation between {frame_index} and {frame_index+1}: c{frame_index}_T_c{frame_index+1} - estimated using PICP')
         print(f'Transformation of frame {frame_index+1}: w_T_c{frame_index+1} = w_T_c{frame_index} c{frame_index}_T_c{frame_index+1}\n')
-        print(f'  - Valid transformation:             {is_valid}')
-        print(f'  - Num iterations:                   {len(iterations_results["T"])}\n')
-        for title, key in (('Error', 'error'), ('Num inliers', 'num_inliers'),
-                           ('Kernel threshold', 'kernel_threshold'), ('Dumping factor', 'dumping_factor')):
-            vals = iterations_results[key]
-            print(f'  - {title} best iteration:  {vals[lo]} (index: {lo})')
-            print(f'  - {title} worst iteration: {vals[hi]} (index: {hi})')
-            print(f'  - Mean {title.lower()}:    {np.round(np.mean(vals), 5)}\n')
+        for line in self.summary_lines(iterations_results, is_valid, lo, hi):
+            print(line)
         print(f'Applied transformation of index {lo} to the camera')
         print('========================================================================================\n')
 
@@ -179,16 +225,12 @@ class ProjectiveICP:
         self.__camera.set_c_T_w(np.linalg.inv(T))
         return T, True, iterations_results
 
-    @staticmethod
-    def history_to_results(hist):
+    summary_lines = staticmethod(lambda results, is_valid, lo, hi: summary_lines(results, is_valid, lo, hi))
+
+    def history_to_results(self, hist):
         """Device history rows -> the reference's iterations_results dict (src/ProjectiveICP.py:173)."""
-        def num(x):
-            return int(x) if float(x).is_integer() else float(x)
-        return {'T': [hist[k, _lib.H_T:_lib.H_T + 16].reshape(4, 4).copy() for k in range(hist.shape[0])],
-                'error': [float(e) for e in hist[:, _lib.H_ERROR]],
-                'num_inliers': [int(n) for n in hist[:, _lib.H_NUM_INLIERS]],
-                'kernel_threshold': [num(t) for t in hist[:, _lib.H_KERNEL_THR]],
-                'dumping_factor': [num(d) for d in hist[:, _lib.H_DAMPING]]}
+        return results_from_history(hist, self.__base_kernel_threshold, self.__min_kernel_threshold,
+                                    self.__base_dumping_factor)
 
     def one_step(self, reference_image_points, current_world_points, w_T_c0, kernel_threshold, dumping_factor):
         """One damped Gauss-Newton step (src/ProjectiveICP.py:260-273).  The camera state used for

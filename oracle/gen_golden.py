@@ -440,6 +440,58 @@ def gen_degenerate(ref_picp_mod, cam, data, geo):
           "n_inside", [out[f"loop{li}_n_inside"].tolist() for li in range(len(starts))])
 
 
+def gen_frame_summary(ref_picp_mod, cam, data):
+    """What the reference's ``update`` prints for a frame (src/ProjectiveICP.py:117-141) and the Python
+    number types of the values in its iteration lists, on three frames of the ground-truth-map run
+    (a straight one, two turning ones).  ``update`` goes on into the OpenCV triangulation when the
+    frame is valid; that call is replaced by one that keeps no point, which changes nothing that is
+    printed.  Also a run with float parameters, where the lists hold floats throughout."""
+    import contextlib
+    import io
+    gt_poses = data.get_trajectory_data_poses()
+    C = np.array(cam.get_camera_transform())
+    world = data.get_world_data()
+    cam0_T_w = np.linalg.inv(gt_poses[0] @ C)
+    wp = np.array(world["position"])
+    map_pos = (cam0_T_w[:3, :3] @ wp.T).T + cam0_T_w[:3, 3]
+    keep_nothing = lambda p0, p1, *a: ([], np.zeros(len(p0), dtype=bool))
+    ref_picp_mod.triangulate_points = keep_nothing
+    out = {}
+    cases = [(0, {}), (16, {}), (70, {}), (16, dict(kernel_threshold=1000.0, min_kernel_threshold=10.0, dumping_factor=64.0))]
+    for ci, (f, over) in enumerate(cases):
+        picp = make_picp(ref_picp_mod, cam, data, **over)
+        m = picp.get_map()
+        m["position"] = [p for p in map_pos]
+        m["appearance"] = [list(a) for a in world["appearance"]]
+        m["error"] = [0.0] * len(m["position"])
+        pose = cam0_T_w @ gt_poses[f] @ C
+        picp._ProjectiveICP__current_pose = pose
+        cam.set_c_T_w(np.linalg.inv(pose))
+        captured = {}
+        inner = picp._ProjectiveICP__projective_ICP
+
+        def spy(meas, frame, inner=inner, captured=captured):
+            r = inner(meas, frame)
+            captured["results"] = r[2]
+            return r
+        picp._ProjectiveICP__projective_ICP = spy
+        text = io.StringIO()
+        cwd = os.getcwd()
+        with contextlib.redirect_stdout(text):
+            picp.update(f)                       # makes outputs/frame_XX under the scratch cwd
+        assert os.getcwd() == cwd
+        r = captured["results"]
+        out[f"case{ci}_frame"] = f
+        out[f"case{ci}_float_parameters"] = bool(over)
+        out[f"case{ci}_text"] = np.array(text.getvalue())
+        for k in ("error", "num_inliers", "kernel_threshold", "dumping_factor"):
+            out[f"case{ci}_{k}"] = np.array(r[k], dtype=np.float64)
+            out[f"case{ci}_{k}_is_int"] = np.array([isinstance(v, (int, np.integer)) for v in r[k]])
+    out["n_cases"] = len(cases)
+    np.savez_compressed(os.path.join(OUT, "ref_frame_summary.npz"), **out)
+    print("frame summary:", [(int(out[f"case{c}_frame"]), len(out[f"case{c}_error"])) for c in range(len(cases))])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_picp_mod, Camera, Data, ref_da, ref_geo = import_reference()
@@ -447,6 +499,9 @@ def main():
         gen_general_camera(ref_picp_mod, Camera, Data, ref_geo)
         return
     cam, data = Camera(), Data()
+    if "--only-frame-summary" in sys.argv:
+        gen_frame_summary(ref_picp_mod, cam, data)
+        return
     if "--only-degenerate" in sys.argv:
         gen_degenerate(ref_picp_mod, cam, data, ref_geo)
         return
@@ -457,6 +512,7 @@ def main():
     gen_gtmap(ref_picp_mod, cam, data)
     gen_general_camera(ref_picp_mod, Camera, Data, ref_geo)
     gen_degenerate(ref_picp_mod, Camera(), Data(), ref_geo)
+    gen_frame_summary(ref_picp_mod, Camera(), Data())
 
 
 if __name__ == "__main__":
