@@ -23,7 +23,9 @@ cpu_baseline = the C restatement of the reference loop (oracle/) on one host cor
 
 --config batched: 4 096 independent problems x 2 048 correspondences, one workgroup each, 20 iterations.
 --config assoc:   appearance association, 10^6 x 10^6 descriptors of 10 doubles.
-Both print one JSON line of the same schema (single GPU).
+Both print one JSON line of the same schema; with --gpus N the batched problems are split over the
+ranks (replicas only, no exchange) and the association shards its query rows (set 2 replicated, the
+index lists all-gathered).
 """
 from __future__ import annotations
 
@@ -232,10 +234,9 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
     return "torch", "; ".join([f"{backend} all-reduces through torch.distributed between stage launches"] + notes)
 
 
-def bench_loop(args):
-    if os.environ.get("PICP_BENCH_DEBUG"):
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["PICP_BENCH_DEBUG"]), exit=True)
+def init_ranks(args):
+    """One process per GPU: reads the launcher's environment, selects this rank's device and joins the
+    process group.  Returns (world, rank, local_rank, backend, single_device)."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,6 +260,27 @@ def bench_loop(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+    return world, rank, local_rank, backend, single_device
+
+
+def max_over_ranks(dt, world, backend):
+    """The slowest rank's time (every rank gets it)."""
+    if world == 1:
+        return dt
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def bench_loop(args):
+    if os.environ.get("PICP_BENCH_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PICP_BENCH_DEBUG"]), exit=True)
+    import torch
+    import torch.distributed as dist
+    world, rank, local_rank, backend, single_device = init_ranks(args)
     from tests.synthetic import true_pose
     pkg = importlib.import_module("monocular-visual-odometry_amd")
     L = pkg._lib
@@ -333,10 +355,7 @@ def bench_loop(args):
     res = run_steps(args.steps, record=True) or res
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, world, backend)
     assert res.num_iterations == ITERATIONS, res.num_iterations
 
     n_local = hi - lo
@@ -434,31 +453,43 @@ def bench_loop(args):
 
 # ---- config 3: batched problems ------------------------------------------------------------------------
 def bench_batched(args):
+    """N > 1: the problems are independent, so the ranks take contiguous shares of them and exchange
+    nothing (replicas only); value = all problems over the slowest rank's time."""
     import torch
+    import torch.distributed as dist
     from oracle import picp_oracle as po
     from oracle import picp_oracle_c as oc
     from tests.synthetic import make_problem
+    world, rank, local_rank, backend, single_device = init_ranks(args)
     pkg = importlib.import_module("monocular-visual-odometry_amd")
     L = pkg._lib
-    ctx = pkg.get_context(0)
+    ctx = pkg.get_context(local_rank)
     cam = L.camera_struct([[180, 0, 320], [0, 180, 240], [0, 0, 1]], 640, 480)
     sched = L.schedule_struct(ITERATIONS, 10, 1000, 10, 2000, 64, 1, 64, True)
-    B, N = 4096, 2048
+    B_all, N = 4096, 2048
+    p_lo, p_hi = pkg.sharded.row_bounds(B_all, rank, world)
+    B = p_hi - p_lo
     uv = np.empty((B * N, 2))
     pw = np.empty((B * N, 3))
     for p in range(B):
-        uv[p * N:(p + 1) * N], pw[p * N:(p + 1) * N], _ = make_problem(N, seed=p)
+        uv[p * N:(p + 1) * N], pw[p * N:(p + 1) * N], _ = make_problem(N, seed=p_lo + p)
     corr = ctx.soa(uv, pw)
     offsets = ctx.to_device(np.arange(B + 1, dtype=np.int64) * N, np.int64)
     poses0 = ctx.to_device(np.tile(np.eye(4).reshape(1, 16), (B, 1)))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(max(args.warmup, 1)):
         results, _ = ctx.run_batched(corr, offsets, poses0, cam, sched, max_count=N)
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         results, _ = ctx.run_batched(corr, offsets, poses0, cam, sched, max_count=N)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    fence()
+    dt = max_over_ranks(time.perf_counter() - t0, world, backend) / args.steps
     # launch duration from events bound to the stream around single launches
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ms = []
@@ -471,27 +502,36 @@ def bench_batched(args):
     launch_ms = float(np.mean(ms))
     r = ctx.decode_results(results.cpu().numpy())
     assert (r["num_iterations"] == ITERATIONS).all() and r["valid"].all()
-    units = B * N * ITERATIONS
+    units = B_all * N * ITERATIONS
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     sq, sq_src = committed_counters("r*_pmc_sq_batched*.json", "icp_batched_resident_kernel")
+    if sq and "SQ_INSTS_VALU" in sq and B != B_all:          # the counter pass ran all 4 096 problems on one GPU
+        sq = {"SQ_INSTS_VALU": float(sq["SQ_INSTS_VALU"]) * B / B_all}
     valu = valu_block(sq, sq_src, launch_ms)
     peak = SIMDS * 16 * CLOCK_HZ / 1e12                          # float64 lane-operations per second, in 1e12
     achieved = (valu["valu_wave_instructions_per_launch"] * 64 / (launch_ms * 1e-3) / 1e12) if valu else None
     out = {"metric": "ICP correspondence-iterations/sec", "value": units / dt, "unit": "correspondence-iterations/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
-           "scaling": None, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"batched independent ICP, {B} problems x {N} correspondences, 20 LM iterations, "
-                                  "one pose per workgroup", "problems": B, "correspondences_per_problem": N,
-                      "lm_iterations": ITERATIONS, "problems_per_s": B / dt},
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+           "scaling": "strong" if world > 1 else None, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"batched independent ICP, {B_all} problems x {N} correspondences, 20 LM iterations, "
+                                  "one pose per workgroup", "problems": B_all, "correspondences_per_problem": N,
+                      "lm_iterations": ITERATIONS, "problems_per_s": B_all / dt,
+                      "collective": None if world == 1 else f"none: replicas only, {B} problems on rank 0"},
            "roofline": {"bound": "fp64_valu", "kernel": "icp_batched_resident_kernel (problem held in registers and LDS)",
                         "achieved": achieved, "peak": peak, "unit": "1e12 float64 lane-operations/s",
                         "frac": (achieved / peak) if achieved else None,
                         "peak_derivation": "1 024 SIMDs x 16 float64 lanes per clock x 2.4 GHz",
                         "mean_launch_ms": launch_ms, "valu": valu, "traffic": None,
                         "hbm_algorithmic_GBs": 40.0 * B * N / (launch_ms * 1e-3) / 1e9,
+                        "problems_per_launch": B,
                         "note": "every correspondence is read from HBM once per solve (40 B); the loop runs on chip, so "
                                 "the bound is the SIMDs' float64 issue rate: executed vector instructions x 64 lanes "
                                 "over the launch duration, instruction count from the committed SQ counter pass"}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         oc.load()
         params = po.IcpParams(num_iterations=ITERATIONS, disable_stop=True)
         n_cpu = 1024
@@ -508,33 +548,56 @@ def bench_batched(args):
 
 # ---- config 5: appearance association ------------------------------------------------------------------
 def bench_assoc(args):
+    """N > 1: the query rows (set 1) are sharded over the ranks, set 2 is replicated; a step is the
+    association of every rank's rows plus the all-gathers that give every rank the whole pair list."""
     import torch
+    import torch.distributed as dist
     from oracle import picp_oracle as po
+    world, rank, local_rank, backend, single_device = init_ranks(args)
     pkg = importlib.import_module("monocular-visual-odometry_amd")
-    ctx = pkg.get_context(0)
+    ctx = pkg.get_context(local_rank)
     n, D = 1_000_000, 10
     rng = np.random.default_rng(7)
     app2 = rng.uniform(-1.0, 1.0, (n, D))
     perm = rng.permutation(n)
     app1 = app2[perm]
-    d1, d2 = ctx.to_device(app1), ctx.to_device(app2)
+    lo, hi = pkg.sharded.row_bounds(n, rank, world)
+    d1, d2 = ctx.to_device(app1[lo:hi]), ctx.to_device(app2)
+
+    def associate():
+        if world == 1:
+            return ctx.associate(d1, d2)
+        return pkg.sharded.associate_sharded(ctx.associate, d1, d2, lo)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     timing = {}
     for mode in ("scan", "hash"):
         ctx.set_association_mode(mode)
         reps = args.steps if mode == "hash" else max(2, min(args.steps, 4))
         for _ in range(max(args.warmup, 1) if mode == "hash" else 1):
-            i1, i2 = ctx.associate(d1, d2)
-        torch.cuda.synchronize()
+            i1, i2 = associate()
+        fence()
         t0 = time.perf_counter()
         for _ in range(reps):
-            i1, i2 = ctx.associate(d1, d2)
-        torch.cuda.synchronize()
-        timing[mode] = (time.perf_counter() - t0) / reps
+            i1, i2 = associate()
+        fence()
+        timing[mode] = max_over_ranks(time.perf_counter() - t0, world, backend) / reps
         assert np.array_equal(i2.cpu().numpy(), perm) and np.array_equal(i1.cpu().numpy(), np.arange(n))
     ctx.set_association_mode("auto")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     pairs = float(n) * n
     dt = timing["hash"]                                           # what picp_associate runs at this size
     sqs, sqs_src = committed_counters("r*_pmc_sq_assoc*.json", "assoc_scan_kernel")
+    if sqs and "SQ_INSTS_VALU" in sqs and world > 1:         # the counter pass ran all the query rows on one GPU
+        sqs = {"SQ_INSTS_VALU": float(sqs["SQ_INSTS_VALU"]) * (hi - lo) / n}
     scan_valu = valu_block(sqs, sqs_src, timing["scan"] * 1e3)
     # the join reads both descriptor sets once and writes / probes an 8-byte-per-slot table, priced at 2 n slots
     # rounded up to a power of two (the library spreads it over 4 n: shorter probe sequences for more bytes, which
@@ -543,12 +606,15 @@ def bench_assoc(args):
     join_bytes = 2 * n * D * 8.0 + 2 * table_bytes + 2 * n * 8.0
     out = {"metric": "appearance-association pair evaluations/sec (N1 x N2 per call: the pairs the reference's double "
                      "loop visits, src/data_association.py:29-31)",
-           "value": pairs / dt, "unit": "pair-evaluations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",
+           "value": pairs / dt, "unit": "pair-evaluations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else None,
+           "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": f"appearance data association, {n} x {n} descriptors of {D} float64, every query has "
                                   "exactly one exact match, projection = 0", "method": "hash join (picp_associate's "
                                   "choice at this size; identical pair list to the all-pairs scan)",
+                      "collective": None if world == 1 else f"query rows sharded over {world} ranks, set 2 replicated; one "
+                                    f"all-gather of the pair counts and one of the index lists per call ({backend})",
                       "all_pairs_scan_ms": timing["scan"] * 1e3, "all_pairs_scan_pair_evaluations_per_s": pairs / timing["scan"]},
            "roofline": {"bound": "hbm", "kernel": "hash_place_kernel + hash_settle_kernel + hash_count_kernel + offsets + hash_emit_kernel (hash join)",
                         "achieved": join_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -558,11 +624,11 @@ def bench_assoc(args):
                                 "once, two index lists; time = whole picp_associate call (five launches and one "
                                 "wait), not one kernel",
                         "all_pairs_scan": {"bound": "int_valu", "valu": scan_valu,
-                                           "instructions_per_pair": (scan_valu["valu_wave_instructions_per_launch"] * 64 / pairs)
+                                           "instructions_per_pair": (scan_valu["valu_wave_instructions_per_launch"] * 64 / (float(hi - lo) * n))
                                            if scan_valu else 1.5,
                                            "note": "exact equality forbids the distance-GEMM form; one 32-bit screening "
                                                    "test per pair on the vector ALU (about 1.5 instructions per pair)"}}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         q = 512
         t0 = time.perf_counter()
         r1, r2 = po.associate(app1[:q], app2, chunk=64)
