@@ -56,8 +56,8 @@ REFERENCE_LOOP_RATE = 1.8e3    # correspondence-iterations/s of the reference's 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=["loop", "batched", "assoc"], default="loop")
     ap.add_argument("--corr", type=int, default=0, help="total correspondences (default 2^20 at 1 GPU, 2^26 sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -363,6 +363,28 @@ def bench_loop(args):
     resident = world == 1 and 0 < M <= ctx.resident_capacity()
     if world == 1:
         run_mean_ms, run_min_ms = time_resident(ctx, pkg, corr, cam, sched)
+    host_buffers = None
+    if world == 1:
+        # A caller that holds the five arrays in (pinned) host memory pays one host-to-device copy of
+        # 40 B per correspondence before each loop; `value` does not include it, this block does.
+        host = torch.empty((5, n_local), dtype=torch.float64).pin_memory()
+        for k in range(5):
+            host[k].copy_(corr[k])
+        dev = torch.empty((5, n_local), dtype=torch.float64, device=corr[0].device)
+        dev.copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dev.copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t0) / reps * 1e3
+        step_ms = dt / args.steps * 1e3
+        host_buffers = {"h2d_ms_per_step": h2d_ms, "h2d_GBs": 40.0 * n_local / (h2d_ms * 1e-3) / 1e9,
+                        "value_including_h2d": M * ITERATIONS / ((h2d_ms + step_ms) * 1e-3),
+                        "note": "five float64 arrays copied from pinned host memory before every loop, copy and loop "
+                                "one after the other; not what `value` reports (inputs resident in HBM)"}
+        del host, dev
     big = None
     if rank == 0 and world == 1 and not args.no_large_scan:
         # the same scan on an input that cannot live in the 256 MB Infinity Cache
@@ -440,6 +462,8 @@ def bench_loop(args):
                          "loop_achieved_GBs": loop_bytes * args.steps / dt / 1e9,
                          "streaming_scan": scan, "streaming_scan_hbm_resident": big},
         }
+        if host_buffers:
+            out["host_buffers"] = host_buffers
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, args.cpu_iterations)
         print(json.dumps(out), flush=True)
