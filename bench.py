@@ -305,7 +305,13 @@ def bench_loop(args):
         res, _ = pkg.sharded.run_sharded(stage_set[0], ITERATIONS, disable_stop=True, native=(mode == "rccl"))
         return res
 
+    peer_calls = [0]
+    fail_at = int(os.environ.get("PICP_BENCH_FAIL_STEP", "0"))   # rehearsal of the fallback: the last rank drops out at this call
+
     def step_peer():
+        peer_calls[0] += 1
+        if fail_at and rank == world - 1 and peer_calls[0] == fail_at:
+            raise L.PicpError("injected failure (PICP_BENCH_FAIL_STEP)")
         return ctx.run_sharded(corr, pose0, cam, sched, want_history=False)[0]
 
     mode, collective = None, None
@@ -318,7 +324,10 @@ def bench_loop(args):
             return plan(pose0)[0]
         return step_peer() if mode == "peer" else step_stages(mode)
 
+    fences = [0]
+
     def fence():
+        fences[0] += 1
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -349,12 +358,38 @@ def bench_loop(args):
             assert last.num_iterations == ITERATIONS, last.num_iterations
         return last
 
-    res = run_steps(args.warmup) or step()
-    fence()
-    t0 = time.perf_counter()
-    res = run_steps(args.steps, record=True) or res
-    fence()
-    dt = time.perf_counter() - t0
+    def timed_region():
+        res = run_steps(args.warmup) or step()
+        fence()
+        t0 = time.perf_counter()
+        res = run_steps(args.steps, record=True) or res
+        fence()
+        return res, time.perf_counter() - t0
+
+    if mode == "peer":
+        # The in-kernel exchange has passed one trial loop, not thousands.  Its waits are bounded, so a
+        # failure shows as an error from a step (on every rank within the same step: a rank that gives up
+        # stops publishing); the steps themselves contain no collective of the process group, so every
+        # rank reaches the agreement below at the same point, and all then repeat the measurement with
+        # the stage launches.
+        before = fences[0]
+        try:
+            res, dt = timed_region()
+            ok = True
+        except L.PicpError as e:
+            print(f"rank {rank}: in-kernel exchange failed during the run: {e}", file=sys.stderr)
+            ok = False
+            while fences[0] < before + 2:              # the barriers a rank without the failure passes through
+                fence()
+        if not pkg.sharded._agree(ok):
+            pkg.sharded.shutdown_peer_exchange(ctx)
+            mode = "torch"
+            collective = (f"{backend} all-reduces through torch.distributed between stage launches; the in-kernel "
+                          "exchange passed its trial loop but failed during the run")
+            launch_ms.clear()
+            res, dt = timed_region()
+    else:
+        res, dt = timed_region()
     dt = max_over_ranks(dt, world, backend)
     assert res.num_iterations == ITERATIONS, res.num_iterations
 
