@@ -359,20 +359,21 @@ def test_64M_correspondences_in_eight_shards_equal_one_array():
     assert int(hist[0, L.H_N_INSIDE]) > 0.9 * M
     assert rel_err(hist8[:, L.H_T:L.H_T + 16], hist[:, L.H_T:L.H_T + 16]) < 1e-9
     assert np.max(np.abs(np.array(list(res8.T)).reshape(4, 4) - T_true)) < 1e-3
-    # the first two iterations of the same 2^26 correspondences through the C restatement of the
+    # the first four iterations of the same 2^26 correspondences through the C restatement of the
     # reference loop (one correspondence at a time, in index order): counts exact, H and poses within 1e-9
     from oracle import picp_oracle_c as oc
     host = [c.cpu().numpy() for c in corr]
     uv = np.stack(host[:2], axis=1)
     pw = np.stack(host[2:], axis=1)
     del host
-    _, _, rows, _ = oc.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=2, disable_stop=True))
+    n_c = 4
+    _, _, rows, _ = oc.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=n_c, disable_stop=True))
     del uv, pw
     for h in (hist, hist8):
         for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_N_STAGE1, L.H_N_STAGE2, L.H_KERNEL_THR, L.H_DAMPING):
-            assert np.array_equal(h[:2, col], rows[:2, col]), col
-        assert rel_err(h[:2, L.H_T:L.H_T + 16], rows[:2, L.H_T:L.H_T + 16]) < 1e-9
-        for k in range(2):
+            assert np.array_equal(h[:n_c, col], rows[:n_c, col]), col
+        assert rel_err(h[:n_c, L.H_T:L.H_T + 16], rows[:n_c, L.H_T:L.H_T + 16]) < 1e-9
+        for k in range(n_c):
             assert entry_err(h[k, L.H_H:L.H_H + 36], rows[k, L.H_H:L.H_H + 36]) < 1e-9, k
 
 
