@@ -199,6 +199,18 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
         return (got.num_iterations == ref.num_iterations and got.best_index == ref.best_index and
                 np.max(np.abs(result_pose(got) - result_pose(ref))) <= 1e-9)
 
+    def loop_ms(fn, n=3):
+        """Wall time of one loop through `fn`, the slowest rank's mean of n (the same number on every rank).
+        `fn` must not fail here: it has just passed its trial on every rank."""
+        import torch
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return max_over_ranks((time.perf_counter() - t0) / n, world, backend) * 1e3
+
     notes = []
     if want in ("auto", "peer") and S.init_peer_exchange(ctx):
         ok, why = True, ""
@@ -208,11 +220,29 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
         except pkg._lib.PicpError as e:
             ok, why = False, f"its trial loop failed ({e})"
         if S._agree(ok):
-            return "peer", "in-kernel exchange through peer memory (HIP IPC, xGMI stores), one launch per loop"
+            # both paths work: keep the in-kernel exchange unless the stage launches are faster on this
+            # machine (they are not where it was rehearsed; between real GPUs the peer stores are untried)
+            text = "in-kernel exchange through peer memory (HIP IPC, xGMI stores), one launch per loop"
+            if want == "peer":
+                return "peer", text
+            try:
+                ms_peer, failed = loop_ms(step_peer), False
+            except pkg._lib.PicpError as e:
+                print(f"rank {rank}: in-kernel exchange failed while being timed: {e}", file=sys.stderr)
+                ms_peer, failed = float("inf"), True
+                max_over_ranks(0.0, world, backend)                  # the collective of loop_ms a rank without the failure is in
+            failed = not S._agree(not failed)
+            ms_stages = loop_ms(lambda: step_stages("torch"))
+            if not failed and ms_peer <= ms_stages:
+                return "peer", f"{text} ({ms_peer:.3f} ms per loop in the trial; stage launches with {backend} all-reduces {ms_stages:.3f} ms)"
+            why = ("it failed while being timed" if failed else
+                   f"the stage launches were faster in the trial ({ms_stages:.3f} ms per loop against {ms_peer:.3f} ms)")
+            notes.append(f"the in-kernel exchange passed its trial but {why}")
+        else:
+            notes.append("the in-kernel exchange was set up but failed its trial")
         if why:
             print(f"rank {rank}: in-kernel exchange not used: {why}", file=sys.stderr)
         S.shutdown_peer_exchange(ctx)
-        notes.append("the in-kernel exchange was set up but failed its trial")
     if want in ("auto", "rccl") and backend == "nccl" and S.init_native_exchange(ctx):
         # one all-reduce of known values through the library's communicator, then a trial loop
         probe = ctx.to_device(np.full(4, float(rank + 1)))
