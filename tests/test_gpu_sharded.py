@@ -202,7 +202,7 @@ def _peer_rank(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_exchange_inside_the_single_launch_loop(world):
     """The sharded single-launch loop with its exchange between the ranks inside the kernel
     (picp_run_sharded), rehearsed with all ranks on the box's one GPU: each rank's exchange memory is

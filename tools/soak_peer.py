@@ -2,7 +2,9 @@
 on ONE GPU (gloo process group, exchange memory mapped through HIP IPC as between GPUs, every kernel
 capped to its share of the compute units): many loops in a row on the same exchange memory, so that the
 alternating slots and the exchange count that runs on from launch to launch are exercised thousands of
-times.  Every loop must return the bits of the first one, on every rank, and no launch may give up.
+times.  Every loop must return the bits of the first one, on every rank, no launch may give up, and the
+first loop must give the counts (exactly) and the pose (1e-9) of the C restatement of the reference loop
+on the unsharded input.
 
     python tools/soak_peer.py [ranks [loops [correspondences ...]]]
 """
@@ -52,7 +54,7 @@ def rank_main(rank, world, port, loops, sizes, out):
                 differing += 1
         dt = time.perf_counter() - t0
         dist.barrier()
-        report.append((M, loops, dt, differing, failed, T0))
+        report.append((M, loops, dt, differing, failed, T0, hist0 if rank == 0 else None))
         if failed:
             break
     out.put((rank, report))
@@ -77,13 +79,23 @@ def main():
     for p in procs:
         p.join(timeout=60)
     bad = 0
-    for i, (M, n, dt, differing, failed, T0) in enumerate(got[0][1]):
+    from oracle import picp_oracle as po
+    from oracle import picp_oracle_c as poc
+    from tests.synthetic import make_problem
+    L = importlib.import_module("monocular-visual-odometry_amd")._lib
+    ints = [L.H_N_INSIDE, L.H_NUM_INLIERS, L.H_N_STAGE1, L.H_N_STAGE2, L.H_KERNEL_THR, L.H_DAMPING]
+    for i, (M, n, dt, differing, failed, T0, hist0) in enumerate(got[0][1]):
+        # the first loop against the C restatement of the reference loop on the whole, unsharded input
+        uv, pw, _ = make_problem(M, seed=[3, M % 1000])
+        T_ref, _, rows, _ = poc.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=20, disable_stop=True))
+        exact = np.array_equal(hist0[:, ints], rows[:, ints]) and np.abs(T0.reshape(4, 4) - T_ref).max() < 1e-9
+        bad += 0 if exact else 1
         same = all(np.array_equal(T0, g[1][i][5]) for g in got[1:] if len(g[1]) > i)
         differ = sum(g[1][i][3] for g in got if len(g[1]) > i)
         fails = sum(g[1][i][4] for g in got if len(g[1]) > i)
         bad += differ + fails + (0 if same else 1)
         print(f"{world} ranks, M={M:9d}: {n} loops x 40 exchanges in {dt:6.2f} s ({dt / n * 1e3:.3f} ms per loop), "
-              f"differing results {differ}, abandoned launches {fails}, ranks agree: {same}")
+              f"differing results {differ}, abandoned launches {fails}, ranks agree: {same}, counts and pose of the C restatement: {exact}")
     sys.exit(1 if bad else 0)
 
 
