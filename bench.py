@@ -264,6 +264,27 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
     return "torch", "; ".join([f"{backend} all-reduces through torch.distributed between stage launches"] + notes)
 
 
+SETTLE_SECONDS = 0.03          # see settle_device
+
+
+def settle_device(step, seconds=SETTLE_SECONDS, most=2000):
+    """Runs `step` back to back for `seconds` of wall time before the warm-up steps.  After an idle period
+    (the set-up of the inputs is one) the device needs about 12 ms of continuous work to reach its steady
+    clocks: measured with events bound to each dispatch, the first ten 2^20 x 20 loops of a process, or
+    after half a second of idling, take 250 us each, the next forty come down to 231 us one by one, and
+    every later one stays there (tools/settle_probe.py).  A run of `--warmup 5 --steps 20` lies inside that
+    ramp from its first to its last loop and would measure the ramp, not the kernel.  The W warm-up steps
+    and the K timed steps follow this phase unchanged; the bench line says how long it was."""
+    t0 = time.perf_counter()
+    n = 0
+    while n < most and time.perf_counter() - t0 < seconds:
+        step()
+        n += 1
+    return {"loops": n, "ms": (time.perf_counter() - t0) * 1e3,
+            "note": "untimed loops run back to back before the warm-up steps until the device has left its clock ramp "
+                    "after idling (about 12 ms of continuous work); the warm-up and timed steps are as requested"}
+
+
 def init_ranks(args):
     """One process per GPU: reads the launcher's environment, selects this rank's device and joins the
     process group.  Returns (world, rank, local_rank, backend, single_device)."""
@@ -396,6 +417,9 @@ def bench_loop(args):
         fence()
         return res, time.perf_counter() - t0
 
+    # one GPU: a loop is a quarter of a millisecond, so the requested warm-up alone would leave the timed steps
+    # inside the device's clock ramp; sharded loops take milliseconds each and their warm-up steps cover it
+    settle = settle_device(step) if world == 1 else None
     if mode == "peer":
         # The in-kernel exchange has passed one trial loop, not thousands.  Its waits are bounded, so a
         # failure shows as an error from a step (on every rank within the same step: a rank that gives up
@@ -527,6 +551,8 @@ def bench_loop(args):
                          "loop_achieved_GBs": loop_bytes * args.steps / dt / 1e9,
                          "streaming_scan": scan, "streaming_scan_hbm_resident": big},
         }
+        if settle:
+            out["settle"] = settle
         if host_buffers:
             out["host_buffers"] = host_buffers
         if world == 1 and not args.no_cpu_baseline:
@@ -571,6 +597,11 @@ def bench_batched(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def synchronous_step():
+        ctx.run_batched(corr, offsets, poses0, cam, sched, max_count=N)
+        torch.cuda.synchronize()
+
+    settle = settle_device(synchronous_step)
     for _ in range(max(args.warmup, 1)):
         results, _ = ctx.run_batched(corr, offsets, poses0, cam, sched, max_count=N)
     fence()
@@ -620,6 +651,7 @@ def bench_batched(args):
                         "note": "every correspondence is read from HBM once per solve (40 B); the loop runs on chip, so "
                                 "the bound is the SIMDs' float64 issue rate: executed vector instructions x 64 lanes "
                                 "over the launch duration, instruction count from the committed SQ counter pass"}}
+    out["settle"] = settle
     if not args.no_cpu_baseline and world == 1:
         oc.load()
         params = po.IcpParams(num_iterations=ITERATIONS, disable_stop=True)
@@ -664,9 +696,12 @@ def bench_assoc(args):
         torch.cuda.synchronize()
 
     timing = {}
+    settle = None
     for mode in ("scan", "hash"):
         ctx.set_association_mode(mode)
         reps = args.steps if mode == "hash" else max(2, min(args.steps, 4))
+        if mode == "hash" and world == 1:
+            settle = settle_device(associate)
         for _ in range(max(args.warmup, 1) if mode == "hash" else 1):
             i1, i2 = associate()
         fence()
@@ -717,6 +752,8 @@ def bench_assoc(args):
                                            if scan_valu else 1.5,
                                            "note": "exact equality forbids the distance-GEMM form; one 32-bit screening "
                                                    "test per pair on the vector ALU (about 1.5 instructions per pair)"}}}
+    if settle:
+        out["settle"] = settle
     if not args.no_cpu_baseline and world == 1:
         q = 512
         t0 = time.perf_counter()
