@@ -535,6 +535,8 @@ def bench_loop(args):
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("synthetic single-pose projective ICP, 2^20 correspondences, 20 LM iterations"
                                     if world == 1 and M == (1 << 20) else
+                                    f"synthetic single-pose projective ICP, {M} correspondences on one GPU, 20 LM iterations"
+                                    if world == 1 else
                                     f"synthetic single-pose projective ICP, {M} correspondences sharded over "
                                     f"{world} GPU(s), 20 LM iterations, 2 exchanges per iteration"),
                        "correspondences": M, "lm_iterations": ITERATIONS,
@@ -551,6 +553,18 @@ def bench_loop(args):
                          "loop_achieved_GBs": loop_bytes * args.steps / dt / 1e9,
                          "streaming_scan": scan, "streaming_scan_hbm_resident": big},
         }
+        if world > 1:
+            # the same workload on ONE GPU, from the committed run of `bench.py --corr <M>`: what strong scaling is
+            # measured against (the N = 1 line of this bench is the 2^20 configuration, which runs on chip)
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_loop_2p26.json")), reverse=True):
+                with open(path) as fh:
+                    one = json.load(fh)
+                if one.get("n_gpus") == 1 and one.get("config", {}).get("correspondences") == M:
+                    out["single_gpu_same_workload"] = {
+                        "value": one["value"], "ms_per_step": one["ms_per_step"], "source": os.path.relpath(path, ROOT),
+                        "speedup": out["value"] / one["value"], "efficiency": out["value"] / one["value"] / world,
+                        "note": "committed measurement of the same correspondences on one MI355X, not taken in this run"}
+                    break
         if settle:
             out["settle"] = settle
         if host_buffers:
