@@ -260,6 +260,9 @@ int picp_sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const d
  *   picp_peer_destroy  unmaps and frees (all ranks must have finished their loops).
  * picp_run_sharded runs the loop on this rank's slice (M may be 0) and synchronises; every rank must
  * call it with the same pose, camera and schedule.  Results as picp_run, identical on all ranks.
+ * A slice that fits the register files of the GPU (picp_resident_capacity) is held on chip for the
+ * whole loop, a larger or empty one is streamed from memory twice per iteration; the two forms run
+ * the same exchanges, so the choice is each rank's own (picp_set_resident_limit(ctx, 0): always stream).
  * Every wait inside the kernel is bounded: if a peer's record does not arrive (a rank died or was
  * never launched) the launch gives up, the call returns PICP_ERR_RETRY and the exchange is unusable
  * until it has been destroyed and set up again; callers then fall back to picp_sharded_rounds.

@@ -101,7 +101,7 @@ int resident_slot_rows(const picp_ctx* ctx); // records to allocate for the in-k
 int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
                      const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
-                     hipEvent_t e1);
+                     hipEvent_t e1, bool sharded = false);
 
 int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                        const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,

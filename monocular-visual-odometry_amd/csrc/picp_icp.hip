@@ -863,8 +863,13 @@ int picp_run_sharded(picp_ctx* ctx, const double* u, const double* v, const doub
         PICP_HIP_CHECK(hipEventCreate(&ctx->prof1));
     }
     hipEvent_t e0 = ctx->time_launches ? ctx->prof0 : nullptr, e1 = ctx->time_launches ? ctx->prof1 : ctx->loop_done;
-    if (int rc = enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
-                                    ctx->pinned, e0, e1, true))
+    // A slice that fits the register files stays on chip for the whole loop, a larger (or empty) one is streamed:
+    // both kernels run the same exchanges between the GPUs, so every rank chooses for its own slice.
+    const bool on_chip = M > 0 && M <= resident_capacity(ctx);
+    if (int rc = on_chip ? enqueue_resident(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist, (int)hist_rows,
+                                            ctx->pinned, e0, e1, true)
+                         : enqueue_persistent(ctx, u, v, x, y, z, M, w_T_c0_host, state, cam, sched, hist,
+                                              (int)hist_rows, ctx->pinned, e0, e1, true))
         return rc;
     PICP_HIP_CHECK(hipEventSynchronize(e1)); // the kernel left the final state in ctx->pinned
     if (e0 != nullptr) {

@@ -363,8 +363,9 @@ __device__ __forceinline__ bool cross_total(double mine, double& out, const Peer
     }
     __syncthreads();
     double tot = 0.0;
-    if (tid < NV)
-        for (int k = 0; k < W; ++k) tot += lds_b[k * CW + tid]; // rank order on every GPU
+    const int lane = tid & 63; // lane t < NV of EVERY wave ends with the total of value t, as after grid_total
+    if (lane < NV)
+        for (int k = 0; k < W; ++k) tot += lds_b[k * CW + lane]; // rank order on every GPU
     out = tot;
     return *lds_flag == 0;
 }
@@ -458,13 +459,18 @@ __device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const 
 // count travels with the first exchange of every iteration, and when it is not zero every workgroup
 // leaves at the same point, workgroup 0 having set the host-visible stop flag to STOP_IMMODERATE; the
 // host then runs the kernel's other form, which makes no assumption.
-template <int R, bool PINHOLE, bool MODERATE>
+// SHARDED: this rank's slice of a sharded run that fits on chip; after every exchange between the
+// workgroups of this GPU one between the GPUs (cross_total), exactly as in icp_persistent_kernel, so a
+// rank may run either kernel on its slice, whatever its peers run.  General form only (not MODERATE).
+template <int R, bool PINHOLE, bool MODERATE, bool SHARDED = false>
 __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                           const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, int64_t M,
                                                           double* __restrict__ state, StartPose pose0, CameraK cam,
                                                           picp_schedule sc, GridExchange gx, double* __restrict__ hist,
-                                                          int hist_rows, double* __restrict__ host_state) {
+                                                          int hist_rows, double* __restrict__ host_state,
+                                                          PeerExchange px) {
+    static_assert(!(SHARDED && MODERATE), "the sharded form has no lean variant");
     __shared__ double st[PICP_STATE_DOUBLES];
     __shared__ double lds[NTR];      // workgroup sums
     __shared__ double lds_fold[NTR]; // folds of the exchanged records (a second buffer spares barriers)
@@ -512,6 +518,7 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
     __syncthreads();
 
     unsigned epoch = 0;
+    [[maybe_unused]] unsigned xepoch = SHARDED ? px.epoch0 : 0u;
 #ifdef PICP_STAMPS
     const unsigned long long core0 = __builtin_amdgcn_s_memtime(), wall0 = __builtin_amdgcn_s_memrealtime();
     // Diagnostic build only: clock stamps of workgroup 0 at the segment boundaries of an iteration,
@@ -580,6 +587,12 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
             } else {
                 __syncthreads(); // every wave has read its totals before stage 2's sum reuses `lds`
             }
+            if constexpr (SHARDED) {
+                if (px.world > 1) {
+                    const double local = g1;
+                    if (!cross_total<NV1>(local, g1, px, xepoch, lds, lds_fold, &flag)) return;
+                }
+            }
         }
         PICP_STAMP(3);
         // The grid totals sit in lanes 0 .. NV1-1 of every wave: read as scalars, no trip through LDS.
@@ -617,6 +630,12 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
             PICP_STAMP(5);
             g2 = tot;
             if (!grid_total<S2_USED, 16>(tot, g2, gx, epoch, lds_fold, &flag)) return;
+            if constexpr (SHARDED) {
+                if (px.world > 1) {
+                    const double local = g2;
+                    if (!cross_total<S2_USED>(local, g2, px, xepoch, lds, lds_fold, &flag)) return;
+                }
+            }
             if ((threadIdx.x & 63) >= S2_USED) g2 = 0.0;
         }
         PICP_STAMP(6);
@@ -636,6 +655,10 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
         }
     }
     __syncthreads(); // the last tail's writes to the state block
+    if constexpr (SHARDED) {
+        if (threadIdx.x == 0) st[ST_XEPOCH] = (double)xepoch; // exchanges between the GPUs so far (next launch's epoch0)
+        __syncthreads();
+    }
 #ifdef PICP_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == 0 && host_state != nullptr && hist != nullptr) {
         // the shader clock the loop actually ran at: core-clock counter against the constant 100 MHz one
@@ -921,6 +944,21 @@ static GridExchange take_slots(picp_ctx* ctx, int grid) {
     return gx;
 }
 
+// The kernels' view of the exchange between the GPUs: none (world 1), or the ctx's connected one.
+static PeerExchange peer_exchange_of(const picp_ctx* ctx, bool sharded) {
+    PeerExchange px;
+    memset(&px, 0, sizeof(px));
+    px.world = 1;
+    if (sharded) {
+        for (int k = 0; k < ctx->peer_world; ++k) px.slots[k] = ctx->peer_slots[k];
+        px.rank = ctx->peer_rank;
+        px.world = ctx->peer_world;
+        px.epoch0 = ctx->peer_epoch;
+        px.spin_limit = ctx->peer_spin_limit;
+    }
+    return px;
+}
+
 int64_t resident_capacity(const picp_ctx* ctx) {
     const int64_t cap = (int64_t)resident_grid(ctx) * NTR * R_MAX;
     return ctx->resident_limit < cap ? ctx->resident_limit : cap;
@@ -930,20 +968,24 @@ template <int R>
 static void launch_resident(picp_ctx* ctx, int grid, const double* u, const double* v, const double* x, const double* y,
                             const double* z, int64_t M, double* state, const StartPose& pose, const picp_camera* cam,
                             const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
-                            hipEvent_t e1) {
+                            hipEvent_t e1, bool sharded = false) {
     const CameraK c = camera_of(cam);
     const GridExchange gx = take_slots(ctx, grid);
+    const PeerExchange px = peer_exchange_of(ctx, sharded);
     // The lean form where it pays (up to R_LEAN_MAX correspondences per thread), unless a recent loop met
-    // immoderate values or the camera matrix itself is not moderate.
-    bool lean = (R <= R_LEAN_MAX) && ctx->full_select_calls == 0;
+    // immoderate values or the camera matrix itself is not moderate.  Sharded: the general form only.
+    bool lean = (R <= R_LEAN_MAX) && ctx->full_select_calls == 0 && !sharded;
     for (int i = 0; i < 9; ++i) lean = lean && fabs(cam->K[i]) < 0x1p199; // moderate(), as the kernel tests its values
-    if ((R <= R_LEAN_MAX) && ctx->full_select_calls > 0) ctx->full_select_calls -= 1;
+    if ((R <= R_LEAN_MAX) && ctx->full_select_calls > 0 && !sharded) ctx->full_select_calls -= 1;
     auto kern = is_pinhole(cam->K) ? (lean ? icp_resident_kernel<R, true, (R <= R_LEAN_MAX)> : icp_resident_kernel<R, true, false>)
                                    : (lean ? icp_resident_kernel<R, false, (R <= R_LEAN_MAX)> : icp_resident_kernel<R, false, false>);
+    if constexpr (R == 2 || R == 8 || R == 16) { // the sizes a sharded run is rounded up to (enqueue_resident)
+        if (sharded) kern = is_pinhole(cam->K) ? icp_resident_kernel<R, true, false, true> : icp_resident_kernel<R, false, false, true>;
+    }
     constexpr unsigned kept_bytes = R * (R <= R_KEEP_MAX ? 4 : 2) * NTR * sizeof(double); // u, v (, chi, 1/z)
     if (kept_bytes > 48 * 1024) { // above the default dynamic-LDS allowance: raise it once per kernel and device
-        static bool raised[4][MAX_DEVICES] = {};
-        const int which = (is_pinhole(cam->K) ? 1 : 0) + (lean ? 2 : 0);
+        static bool raised[8][MAX_DEVICES] = {};
+        const int which = (is_pinhole(cam->K) ? 1 : 0) + (lean ? 2 : 0) + (sharded ? 4 : 0);
         if (ctx->device >= MAX_DEVICES || !raised[which][ctx->device]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)kept_bytes);
@@ -952,10 +994,10 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
     }
     if (e0 != nullptr || e1 != nullptr) // events bound to this dispatch: no marker packet of their own on the stream
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, e0, e1, 0, u, v, x, y, z, M, state, pose, c,
-                              *sched, gx, hist, hist_rows, host_state);
+                              *sched, gx, hist, hist_rows, host_state, px);
     else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NTR), kept_bytes, ctx->stream, u, v, x, y, z, M, state, pose, c, *sched,
-                           gx, hist, hist_rows, host_state);
+                           gx, hist, hist_rows, host_state, px);
 }
 
 // Enqueues the loop, starting from w_T_c0_host.  Precondition:
@@ -965,9 +1007,11 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
 int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, double* state, const picp_camera* cam,
                      const picp_schedule* sched, double* hist, int hist_rows, double* host_state, hipEvent_t e0,
-                     hipEvent_t e1) {
+                     hipEvent_t e1, bool sharded) {
     PICP_REQUIRE(M > 0 && M <= resident_capacity(ctx), "resident loop: %lld correspondences exceed the capacity",
                  (long long)M);
+    PICP_REQUIRE(!sharded || (ctx->peer_connected && !ctx->peer_broken),
+                 "sharded loop: the exchange between the GPUs is not usable");
     // fewest correspondences per thread that still fit one workgroup per CU, then no more
     // workgroups than that R needs
     // ... except that up to SINGLE_WG_MAX correspondences one workgroup does everything: a few more
@@ -979,6 +1023,7 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     int R = 16;
     for (int k = 7; k >= 0; --k)
         if (steps[k] >= per_thread) R = steps[k];
+    if (sharded) R = per_thread <= 2 ? 2 : (per_thread <= 8 ? 8 : 16); // three instantiations of the sharded form
     const int grid = (int)((M + (int64_t)NTR * R - 1) / ((int64_t)NTR * R));
     PICP_REQUIRE(grid >= 1 && grid <= resident_grid(ctx), "resident loop: grid %d does not fit %d CUs", grid,
                  resident_grid(ctx));
@@ -986,7 +1031,7 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
     StartPose pose;
     memcpy(pose.m, w_T_c0_host, sizeof(pose.m));
 #define PICP_RESIDENT_CASE(RR) \
-    case RR: launch_resident<RR>(ctx, grid, u, v, x, y, z, M, state, pose, cam, sched, hist, hist_rows, host_state, e0, e1); break;
+    case RR: launch_resident<RR>(ctx, grid, u, v, x, y, z, M, state, pose, cam, sched, hist, hist_rows, host_state, e0, e1, sharded); break;
     switch (R) {
         PICP_RESIDENT_CASE(1)
         PICP_RESIDENT_CASE(2)
@@ -996,7 +1041,7 @@ int enqueue_resident(picp_ctx* ctx, const double* u, const double* v, const doub
         PICP_RESIDENT_CASE(8)
         PICP_RESIDENT_CASE(12)
     default:
-        launch_resident<16>(ctx, grid, u, v, x, y, z, M, state, pose, cam, sched, hist, hist_rows, host_state, e0, e1);
+        launch_resident<16>(ctx, grid, u, v, x, y, z, M, state, pose, cam, sched, hist, hist_rows, host_state, e0, e1, sharded);
         break;
     }
 #undef PICP_RESIDENT_CASE
@@ -1019,18 +1064,10 @@ int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const do
     StartPose pose;
     memcpy(pose.m, w_T_c0_host, sizeof(pose.m));
     const CameraK c = camera_of(cam);
+    PICP_REQUIRE(!sharded || (ctx->peer_connected && !ctx->peer_broken),
+                 "sharded loop: the exchange between the GPUs is not usable");
     const GridExchange gx = take_slots(ctx, grid);
-    PeerExchange px;
-    memset(&px, 0, sizeof(px));
-    px.world = 1;
-    if (sharded) {
-        PICP_REQUIRE(ctx->peer_connected && !ctx->peer_broken, "sharded loop: the exchange between the GPUs is not usable");
-        for (int k = 0; k < ctx->peer_world; ++k) px.slots[k] = ctx->peer_slots[k];
-        px.rank = ctx->peer_rank;
-        px.world = ctx->peer_world;
-        px.epoch0 = ctx->peer_epoch;
-        px.spin_limit = ctx->peer_spin_limit;
-    }
+    const PeerExchange px = peer_exchange_of(ctx, sharded);
     const bool pin = is_pinhole(cam->K);
     const bool rev = stage2_reverse(ctx, M);
     auto kern = rev ? (pin ? icp_persistent_kernel<true, true> : icp_persistent_kernel<false, true>)

@@ -165,6 +165,10 @@ def _peer_rank(rank, world, port, out):
     p = importlib.import_module("monocular-visual-odometry_amd")
     ctx = p._lib.Context(0)
     ctx.set_grid_limit(int(os.environ.get("PICP_TEST_PEER_GRID", 192 // world)))
+    if os.environ.get("PICP_TEST_PEER_STREAMED") == "1":
+        ctx.set_resident_limit(0)                                # every slice through the streaming form of the loop
+    elif os.environ.get("PICP_TEST_PEER_STREAMED") == "mixed" and rank % 2 == 1:
+        ctx.set_resident_limit(0)                                # odd ranks stream, even ranks hold their slice on chip
     ok = p.sharded.init_peer_exchange(ctx)
     results = []
     if ok:
@@ -202,14 +206,18 @@ def _peer_rank(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_ranks_exchange_inside_the_single_launch_loop(world):
+@pytest.mark.parametrize("world,streamed", [(2, "0"), (2, "1"), (3, "mixed"), (3, "1"), (8, "0")])
+def test_ranks_exchange_inside_the_single_launch_loop(world, streamed, monkeypatch):
     """The sharded single-launch loop with its exchange between the ranks inside the kernel
     (picp_run_sharded), rehearsed with all ranks on the box's one GPU: each rank's exchange memory is
     mapped into the others through HIP IPC exactly as between GPUs, and the kernels run at the same
     time.  Counts, thresholds, damping and iteration counts equal the oracle's, poses within 1e-9, and
     all ranks end with bit-identical results -- over several launches on the same exchange memory,
-    ragged and empty shards, zero-inlier iterations and the fallback to the stage-1 set."""
+    ragged and empty shards, zero-inlier iterations and the fallback to the stage-1 set.
+    streamed "0": every rank holds its slice on chip where it fits (an empty slice is always streamed);
+    "1": every rank streams its slice; "mixed": odd ranks stream, even ranks hold theirs on chip -- the
+    two forms of the loop run the same exchanges, so ranks may differ."""
+    monkeypatch.setenv("PICP_TEST_PEER_STREAMED", streamed)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

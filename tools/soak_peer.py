@@ -30,6 +30,8 @@ def rank_main(rank, world, port, loops, sizes, out):
     L = p._lib
     ctx = L.Context(0)
     ctx.set_grid_limit(192 // world)
+    if os.environ.get("PICP_SOAK_STREAMED") == "1":            # every slice through the streaming form of the loop
+        ctx.set_resident_limit(0)
     assert p.sharded.init_peer_exchange(ctx), "the exchange could not be set up"
     cam = L.camera_struct([[180, 0, 320], [0, 180, 240], [0, 0, 1]], 640, 480)
     sched = L.schedule_struct(20, 10, 1000, 10, 2000, 64, 1, 64, disable_stop=True)
