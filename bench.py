@@ -450,6 +450,7 @@ def bench_loop(args):
     n_local = hi - lo
     s2_mean_ms, s2_min_ms = time_stage2(ctx, pkg, corr, cam, sched)
     resident = world == 1 and 0 < M <= ctx.resident_capacity()
+    shard_on_chip = world > 1 and mode == "peer" and 0 < n_local <= ctx.resident_capacity()   # rank 0's slice
     if world == 1:
         run_mean_ms, run_min_ms = time_resident(ctx, pkg, corr, cam, sched)
     host_buffers = None
@@ -517,8 +518,10 @@ def bench_loop(args):
         elif mode == "peer":
             mean_ms = sum(launch_ms) / max(len(launch_ms), 1)
             achieved = loop_bytes / (mean_ms * 1e-3) / 1e9
-            roof = {"kernel": "icp_persistent_kernel, sharded (whole loop in one launch per rank, arrays streamed twice "
-                              "per iteration, sums exchanged between the GPUs inside the kernel); rank 0's launches",
+            roof = {"kernel": ("icp_resident_kernel, sharded (whole loop in one launch per rank, the slice held on chip, "
+                               "sums exchanged between the GPUs inside the kernel); rank 0's launches" if shard_on_chip else
+                               "icp_persistent_kernel, sharded (whole loop in one launch per rank, arrays streamed twice "
+                               "per iteration, sums exchanged between the GPUs inside the kernel); rank 0's launches"),
                     "bytes_per_launch": loop_bytes, "mean_launch_ms": mean_ms, "min_launch_ms": min(launch_ms)}
         else:
             achieved = scan["achieved"]
@@ -541,7 +544,7 @@ def bench_loop(args):
                                     f"{world} GPU(s), 20 LM iterations, 2 exchanges per iteration"),
                        "correspondences": M, "lm_iterations": ITERATIONS,
                        "steps_in_flight": 2 if (world == 1 and os.environ.get("PICP_BENCH_PIPELINE", "1") != "0") else 1,
-                       "device_path": ("single launch, register-resident" if resident else
+                       "device_path": ("single launch, register-resident" if (resident or shard_on_chip) else
                                        "single launch, arrays streamed twice per iteration" if (world == 1 or mode == "peer")
                                        else "streaming stage launches"),
                        "collective": collective,
