@@ -224,7 +224,7 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
             # machine (they are not where it was rehearsed; between real GPUs the peer stores are untried)
             text = "in-kernel exchange through peer memory (HIP IPC, xGMI stores), one launch per loop"
             if want == "peer":
-                return "peer", text
+                return "peer", text, None
             try:
                 ms_peer, failed = loop_ms(step_peer), False
             except pkg._lib.PicpError as e:
@@ -234,7 +234,8 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
             failed = not S._agree(not failed)
             ms_stages = loop_ms(lambda: step_stages("torch"))
             if not failed and ms_peer <= ms_stages:
-                return "peer", f"{text} ({ms_peer:.3f} ms per loop in the trial; stage launches with {backend} all-reduces {ms_stages:.3f} ms)"
+                return "peer", (f"{text} ({ms_peer:.3f} ms per loop in the trial; stage launches with {backend} "
+                                f"all-reduces {ms_stages:.3f} ms)"), ms_peer
             why = ("it failed while being timed" if failed else
                    f"the stage launches were faster in the trial ({ms_stages:.3f} ms per loop against {ms_peer:.3f} ms)")
             notes.append(f"the in-kernel exchange passed its trial but {why}")
@@ -258,10 +259,10 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
             ok = S._agree(ok)
         if ok:
             return "rccl", "; ".join(["rccl all-reduces enqueued by the library on the kernels' stream, two launches per "
-                                      "iteration"] + notes)
+                                      "iteration"] + notes), None
         S.shutdown_native_exchange(ctx)
         notes.append("the library's own RCCL communicator failed its trial")
-    return "torch", "; ".join([f"{backend} all-reduces through torch.distributed between stage launches"] + notes)
+    return "torch", "; ".join([f"{backend} all-reduces through torch.distributed between stage launches"] + notes), None
 
 
 SETTLE_SECONDS = 0.03          # see settle_device
@@ -365,10 +366,10 @@ def bench_loop(args):
             raise L.PicpError("injected failure (PICP_BENCH_FAIL_STEP)")
         return ctx.run_sharded(corr, pose0, cam, sched, want_history=False)[0]
 
-    mode, collective = None, None
+    mode, collective, trial_ms = None, None, None
     if world > 1:
         ctx.lib.picp_set_launch_timing(ctx.handle, 1)
-        mode, collective = choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages)
+        mode, collective, trial_ms = choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages)
 
     def step():
         if world == 1:
@@ -410,6 +411,15 @@ def bench_loop(args):
         return last
 
     def timed_region():
+        if world == 1:
+            settle_info.update(settle_device(step))
+        else:
+            t0 = time.perf_counter()
+            for _ in range(sharded_settle_loops):
+                step()
+            settle_info.update({"loops": sharded_settle_loops, "ms": (time.perf_counter() - t0) * 1e3,
+                                "note": "untimed loops before the warm-up steps (the device's clock ramp after idling), "
+                                        "the same number on every rank"})
         res = run_steps(args.warmup) or step()
         fence()
         t0 = time.perf_counter()
@@ -418,8 +428,13 @@ def bench_loop(args):
         return res, time.perf_counter() - t0
 
     # one GPU: a loop is a quarter of a millisecond, so the requested warm-up alone would leave the timed steps
-    # inside the device's clock ramp; sharded loops take milliseconds each and their warm-up steps cover it
-    settle = settle_device(step) if world == 1 else None
+    # inside the device's clock ramp.  Sharded: every step is an exchange between the ranks, so all ranks run the
+    # same number of them (from the trial's loop time, which is the slowest rank's and the same number everywhere).
+    settle_info = {}
+    sharded_settle_loops = 0
+    if world > 1:
+        sharded_settle_loops = int(min(max(np.ceil(SETTLE_SECONDS * 1e3 / trial_ms), 1), 500)) if trial_ms else 10
+
     if mode == "peer":
         # The in-kernel exchange has passed one trial loop, not thousands.  Its waits are bounded, so a
         # failure shows as an error from a step (on every rank within the same step: a rank that gives up
@@ -568,8 +583,8 @@ def bench_loop(args):
                         "speedup": out["value"] / one["value"], "efficiency": out["value"] / one["value"] / world,
                         "note": "committed measurement of the same correspondences on one MI355X, not taken in this run"}
                     break
-        if settle:
-            out["settle"] = settle
+        if settle_info:
+            out["settle"] = settle_info
         if host_buffers:
             out["host_buffers"] = host_buffers
         if world == 1 and not args.no_cpu_baseline:
