@@ -277,11 +277,15 @@ def settle_device(step, seconds=SETTLE_SECONDS, most=2000):
     ramp from its first to its last loop and would measure the ramp, not the kernel.  The W warm-up steps
     and the K timed steps follow this phase unchanged; the bench line says how long it was."""
     t0 = time.perf_counter()
-    n = 0
-    while n < most and time.perf_counter() - t0 < seconds:
+    stamps = [t0]
+    while len(stamps) - 1 < most and stamps[-1] - t0 < seconds:
         step()
-        n += 1
-    return {"loops": n, "ms": (time.perf_counter() - t0) * 1e3,
+        stamps.append(time.perf_counter())
+    n = len(stamps) - 1
+    k = min(10, n)
+    return {"loops": n, "ms": (stamps[-1] - t0) * 1e3,
+            "first_loops_ms_per_loop": (stamps[k] - stamps[0]) / k * 1e3,      # synchronous calls, one after the other:
+            "last_loops_ms_per_loop": (stamps[-1] - stamps[-1 - k]) / k * 1e3,   # the ramp shows as the difference
             "note": "untimed loops run back to back before the warm-up steps until the device has left its clock ramp "
                     "after idling (about 12 ms of continuous work); the warm-up and timed steps are as requested"}
 
