@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--corr", type=int, default=0, help="total correspondences (default 2^20 at 1 GPU, 2^26 sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-scan", action="store_true", help="skip the 2^24-correspondence stage-2 timing")
+    ap.add_argument("--no-single-gpu", action="store_true",
+                    help="sharded runs: skip rank 0's run of the whole workload on its one GPU")
     ap.add_argument("--cpu-iterations", type=int, default=300)
     return ap.parse_args()
 
@@ -176,6 +178,58 @@ def cpu_baseline(M, iterations):
                       f"(src/ProjectiveICP.py:286-317) ran at about {REFERENCE_LOOP_RATE:.3g} correspondence-iterations/s "
                       "in the build container (1 thread) and cannot run on the GPU box",
             "numpy_restatement_value": M * n_np / dt_np, "reference_python_loop_value": REFERENCE_LOOP_RATE}
+
+
+def single_gpu_same_workload(ctx, M, cam, sched, pose0, sharded_result, single_device, world, steps=5):
+    """Rank 0 alone, the other ranks waiting at a barrier: the whole M-correspondence problem (the same
+    seeded data the shards hold) through picp_run on this one GPU, `steps` synchronous loops after two
+    untimed ones.  Returns the block the sharded bench line carries as `single_gpu_same_workload`."""
+    import torch
+    if single_device:
+        ctx.set_grid_limit(0)                       # rehearsal on one GPU: the other ranks are idle now
+    whole = device_problem(ctx, M, 0, M)
+    plan = ctx.plan(whole, cam, sched)
+    for _ in range(2):
+        one = plan(pose0)[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one = plan(pose0)[0]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    diff = float(np.max(np.abs(result_pose(one) - result_pose(sharded_result))))
+    block = {"value": M * ITERATIONS / dt, "ms_per_step": dt * 1e3, "steps": steps, "correspondences": M,
+             "max_pose_difference_to_sharded_result": diff,
+             "same_best_index": int(one.best_index) == int(sharded_result.best_index),
+             "note": "measured in this run: rank 0's GPU alone on the same correspondences (picp_run, one launch per "
+                     "loop), the other ranks idle at a barrier"}
+    del plan, whole
+    torch.cuda.empty_cache()
+    if single_device:
+        ctx.set_grid_limit(192 // world)
+    if diff > 1e-9:
+        raise SystemExit(f"the sharded loop's pose differs from the one-GPU loop's on the same correspondences by {diff:.3g}")
+    return block
+
+
+def headline_roofline(algorithmic_GBs, roof):
+    """bound / achieved / peak / unit / frac of a loop line.  A kernel that streams the arrays is priced against
+    HBM with the algorithmic bytes.  The on-chip loop reads HBM once per launch, so pricing its 80 B per
+    correspondence-iteration against HBM says nothing about the kernel (the figure can even pass 1): its bound is
+    the SIMDs' float64 issue rate, and the headline is executed vector lane-operations over that peak (the
+    instruction count from the committed SQ counter pass); the algorithmic-bytes equivalence stays beside it as
+    algorithmic_GBs / algorithmic_frac."""
+    valu = roof.get("valu")
+    if "hbm_bytes_read_once" in roof and valu:
+        peak = SIMDS * 16 * CLOCK_HZ / 1e12
+        achieved = valu["valu_wave_instructions_per_launch"] * 64 / (roof["mean_launch_ms"] * 1e-3) / 1e12
+        return {"bound": "fp64_valu", "achieved": achieved, "peak": peak, "unit": "1e12 float64 lane-operations/s",
+                "frac": achieved / peak, "frac_real_bound": valu["valu_utilisation"],
+                "peak_derivation": "1 024 SIMDs x 16 float64 lanes per clock x 2.4 GHz",
+                "algorithmic_GBs": algorithmic_GBs, "algorithmic_frac": algorithmic_GBs / HBM_PEAK_GBS,
+                "algorithmic_peak_GBs": HBM_PEAK_GBS}
+    return {"bound": "hbm", "achieved": algorithmic_GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": algorithmic_GBs / HBM_PEAK_GBS}
 
 
 def result_pose(res):
@@ -309,6 +363,9 @@ def init_ranks(args):
     single_device = os.environ.get("PICP_BENCH_SINGLE_DEVICE") == "1"
     if single_device:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible "
+                         "(PICP_BENCH_SINGLE_DEVICE=1 PICP_BENCH_BACKEND=gloo rehearses the ranks on one GPU)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -466,6 +523,26 @@ def bench_loop(args):
     dt = max_over_ranks(dt, world, backend)
     assert res.num_iterations == ITERATIONS, res.num_iterations
 
+    # Sharded: (1) every rank must have ended the timed steps with the same 96-double loop state, bit for bit
+    # (the sums are added in rank order on every rank and the solve is deterministic); a peer store that did
+    # not arrive whole, or arrived on one rank only, shows here and fails the run.  (2) rank 0 then runs the
+    # SAME correspondences alone, so that the line carries its own one-GPU figure for this workload.
+    replicas = single = None
+    if world > 1:
+        final_state = ctx._run_state if mode == "peer" else stage_set[0].state
+        same_state, c_lo, c_hi = pkg.sharded.replicas_identical(final_state)
+        replicas = {"replicas_identical": same_state, "state_checksum": f"{c_lo:#x}",
+                    "note": "checksum of the final loop state (96 doubles) of the last timed step, maximum and minimum "
+                            "over the ranks compared"}
+        if not same_state:
+            raise SystemExit(f"rank {rank}: the ranks ended with different loop states (checksums {c_lo:#x} .. {c_hi:#x}): "
+                             "the exchange between the GPUs delivered different sums to different ranks")
+        if not args.no_single_gpu:
+            dist.barrier()
+            if rank == 0:
+                single = single_gpu_same_workload(ctx, M, cam, sched, pose0, res, single_device, world)
+            dist.barrier()
+
     n_local = hi - lo
     s2_mean_ms, s2_min_ms = time_stage2(ctx, pkg, corr, cam, sched)
     resident = world == 1 and 0 < M <= ctx.resident_capacity()
@@ -521,9 +598,10 @@ def bench_loop(args):
                     "hbm_utilisation_real": once / (run_mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "real_bound": "fp64 vector issue of the two stages plus the latency of the in-kernel "
                                   "reductions, exchanges and the solve step; not HBM",
-                    "note": "achieved/frac price the reference's data flow (80 B per correspondence-iteration, two "
-                            "40 B passes) against HBM, as the metric asks; the kernel itself reads each array once per "
-                            "launch (hbm_utilisation_real) and is bound as real_bound says (valu)"}
+                    "note": "algorithmic_GBs / algorithmic_frac price the reference's data flow (80 B per "
+                            "correspondence-iteration, two 40 B passes) against HBM, as the metric asks; the kernel itself "
+                            "reads each array once per launch (hbm_utilisation_real) and is bound as real_bound says, "
+                            "which is what bound / achieved / frac report"}
             if M == (1 << 20):
                 tr, traffic_source = committed_counters("r*_pmc_traffic_loop*.json|r*_pmc_traffic_2p20*.json", "icp_resident_kernel")
                 traffic = tr["hbm_bytes_per_launch"] if tr else None
@@ -568,25 +646,20 @@ def bench_loop(args):
                                        else "streaming stage launches"),
                        "collective": collective,
                        "final_pose_error": float(np.max(np.abs(result_pose(res) - true_pose())))},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "roofline": {**headline_roofline(achieved, roof), "traffic": traffic, "traffic_source": traffic_source,
                          **roof,
                          "loop_bytes_per_corr_iteration": 2 * BYTES_PER_CORR_PER_SCAN,
                          "loop_achieved_GBs": loop_bytes * args.steps / dt / 1e9,
                          "streaming_scan": scan, "streaming_scan_hbm_resident": big},
         }
-        if world > 1:
-            # the same workload on ONE GPU, from the committed run of `bench.py --corr <M>`: what strong scaling is
-            # measured against (the N = 1 line of this bench is the 2^20 configuration, which runs on chip)
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_loop_2p26.json")), reverse=True):
-                with open(path) as fh:
-                    one = json.load(fh)
-                if one.get("n_gpus") == 1 and one.get("config", {}).get("correspondences") == M:
-                    out["single_gpu_same_workload"] = {
-                        "value": one["value"], "ms_per_step": one["ms_per_step"], "source": os.path.relpath(path, ROOT),
-                        "speedup": out["value"] / one["value"], "efficiency": out["value"] / one["value"] / world,
-                        "note": "committed measurement of the same correspondences on one MI355X, not taken in this run"}
-                    break
+        if replicas:
+            out.update(replicas)
+        if single:
+            # what strong scaling is measured against: the N = 1 line of this bench is the 2^20 configuration, which
+            # runs on chip, not this workload
+            single["speedup"] = out["value"] / single["value"]
+            single["efficiency"] = single["speedup"] / world
+            out["single_gpu_same_workload"] = single
         if settle_info:
             out["settle"] = settle_info
         if host_buffers:
@@ -668,6 +741,7 @@ def bench_batched(args):
     if sq and "SQ_INSTS_VALU" in sq and B != B_all:          # the counter pass ran all 4 096 problems on one GPU
         sq = {"SQ_INSTS_VALU": float(sq["SQ_INSTS_VALU"]) * B / B_all}
     valu = valu_block(sq, sq_src, launch_ms)
+    tr, tr_src = committed_counters("r*_pmc_traffic_batched*.json", "icp_batched_resident_kernel")
     peak = SIMDS * 16 * CLOCK_HZ / 1e12                          # float64 lane-operations per second, in 1e12
     achieved = (valu["valu_wave_instructions_per_launch"] * 64 / (launch_ms * 1e-3) / 1e12) if valu else None
     out = {"metric": "ICP correspondence-iterations/sec", "value": units / dt, "unit": "correspondence-iterations/s",
@@ -681,7 +755,8 @@ def bench_batched(args):
                         "achieved": achieved, "peak": peak, "unit": "1e12 float64 lane-operations/s",
                         "frac": (achieved / peak) if achieved else None,
                         "peak_derivation": "1 024 SIMDs x 16 float64 lanes per clock x 2.4 GHz",
-                        "mean_launch_ms": launch_ms, "valu": valu, "traffic": None,
+                        "mean_launch_ms": launch_ms, "valu": valu,
+                        "traffic": (tr["hbm_bytes_per_launch"] * B / B_all) if tr else None, "traffic_source": tr_src,
                         "hbm_algorithmic_GBs": 40.0 * B * N / (launch_ms * 1e-3) / 1e9,
                         "problems_per_launch": B,
                         "note": "every correspondence is read from HBM once per solve (40 B); the loop runs on chip, so "
@@ -764,6 +839,19 @@ def bench_assoc(args):
     # are its own affair), and writes the two index lists
     table_bytes = 8.0 * (1 << int(np.ceil(np.log2(2 * n))))
     join_bytes = 2 * n * D * 8.0 + 2 * table_bytes + 2 * n * 8.0
+    # counter traffic of one join call: the kernels of the join, each at its per-launch figure from the committed
+    # FETCH_SIZE / WRITE_SIZE passes of this command (one launch of each per call; the table clear runs behind the call)
+    join_traffic = join_traffic_src = join_traffic_by_kernel = None
+    if world == 1:
+        parts = {}
+        for kern in ("hash_place_kernel", "hash_settle_kernel", "hash_count_kernel", "scan_block_offsets_kernel",
+                     "hash_emit_kernel", "hash_clear_kernel"):
+            v, src = committed_counters("r*_pmc_traffic_assoc*.json", kern)
+            if v:
+                parts[kern] = v["hbm_bytes_per_launch"]
+                join_traffic_src = src
+        if parts:
+            join_traffic, join_traffic_by_kernel = sum(parts.values()), parts
     out = {"metric": "appearance-association pair evaluations/sec (N1 x N2 per call: the pairs the reference's double "
                      "loop visits, src/data_association.py:29-31)",
            "value": pairs / dt, "unit": "pair-evaluations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -778,7 +866,8 @@ def bench_assoc(args):
                       "all_pairs_scan_ms": timing["scan"] * 1e3, "all_pairs_scan_pair_evaluations_per_s": pairs / timing["scan"]},
            "roofline": {"bound": "hbm", "kernel": "hash_place_kernel + hash_settle_kernel + hash_count_kernel + offsets + hash_emit_kernel (hash join)",
                         "achieved": join_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": join_bytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": join_bytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": join_traffic,
+                        "traffic_source": join_traffic_src, "traffic_by_kernel": join_traffic_by_kernel,
                         "bytes_per_call": join_bytes,
                         "note": "algorithmic bytes of the join: both descriptor sets once, the table written and probed "
                                 "once, two index lists; time = whole picp_associate call (five launches and one "
@@ -804,8 +893,32 @@ def bench_assoc(args):
     print(json.dumps(out), flush=True)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: this process starts the N ranks itself (one
+    process per GPU under torch.distributed.run, rendezvous on 127.0.0.1) and hands their exit status on.
+    It never touches the GPU, nor imports torch: the children are started before anything could initialise
+    a device here, and nothing is exec'ed.  Rank 0's JSON line reaches stdout through the inherited pipe."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL and the peer exchange need here
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     if args.config == "batched":
         return bench_batched(args)
     if args.config == "assoc":

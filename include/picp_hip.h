@@ -231,7 +231,9 @@ int picp_profile_stage2(picp_ctx* ctx, const double* u, const double* v, const d
  * on this rank's slice (s1, s2: device, PICP_S1_DOUBLES / PICP_S2_DOUBLES doubles); with no
  * communicator the all-reduces are skipped.  Every rank must enqueue the same number of
  * rounds: the replicated state is identical on all ranks, so a stop flag read back on one is the
- * same on all (rounds after the stop are no-ops apart from the exchange).  Does not synchronise. */
+ * same on all (rounds after the stop are no-ops apart from the exchange: the scans no longer rewrite
+ * s1 / s2, whose contents are undefined from then on -- every further all-reduce sums the stale
+ * records once more).  Does not synchronise. */
 #define PICP_COMM_ID_BYTES 128
 int picp_comm_unique_id(void* id_host, int64_t bytes);
 int picp_comm_init(picp_ctx* ctx, const void* id_host, int32_t rank, int32_t world);
@@ -266,6 +268,10 @@ int picp_sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const d
  * Every wait inside the kernel is bounded: if a peer's record does not arrive (a rank died or was
  * never launched) the launch gives up, the call returns PICP_ERR_RETRY and the exchange is unusable
  * until it has been destroyed and set up again; callers then fall back to picp_sharded_rounds.
+ * The status is this rank's own: a rank can give up at the last exchange after publishing its record
+ * while a slower rank still completes.  Ranks must therefore agree on the outcome (a logical AND over
+ * their statuses, through whatever process group they have) BEFORE any of them acts on it, and fall
+ * back together (the package's sharded.run_peer does this).
  * picp_peer_world: ranks of a usable exchange, 0 if there is none. */
 #define PICP_PEER_MAX_RANKS 8
 #define PICP_PEER_HANDLE_BYTES 64
@@ -302,7 +308,7 @@ int picp_linearize(picp_ctx* ctx, const double* u, const double* v, const double
  * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference; it
  * computes what picp_linearize computes, with the same kernels, but every intermediate (the state
  * block, the per-workgroup records of both scans, the folded records) lives in a device array that is
- * part of the library's code object (146 KiB on every GPU the library runs on, held until the process
+ * part of the library's code object (322 KiB on every GPU the library runs on, held until the process
  * ends), and the results go to caller-owned DEVICE memory instead of host variables:
  *   out[0..35] H row-major, out[36..41] b, out[42] num_inliers, out[43] error, out[44] n_inside,
  *   out[45..47] zero                                         (PICP_LINEARIZE_OUT_DOUBLES doubles).

@@ -46,9 +46,12 @@ def results_from_history(hist, base_kernel_threshold, min_kernel_threshold, base
     The reference's threshold and damping values are Python numbers whose type follows its
     arithmetic: the threshold keeps the type it has under ``+= 10`` / ``-= 10`` and takes the type
     of ``min_kernel_threshold`` when every pair is an inlier (:200-205); the damping factor stays
-    what the caller passed until the first ``/= 2`` or ``*= 2`` makes it a float for good
-    (:224-225).  Integer parameters (the YAML's) therefore give ``990`` and ``32.0``, not
-    ``990.0`` and ``32``; the lists here carry the same types."""
+    what the caller passed until the first ``/= 2`` makes it a float for good, while ``*= 2`` keeps
+    an int an int (:224-225; a halving and a doubling never fall into one iteration, since the
+    former needs ``stuck > 10`` or both counters at zero and the latter ``flicker > 10``, and each
+    counter is reset whenever the other one's condition holds).  Integer parameters (the YAML's)
+    therefore give ``990`` and ``32.0``, not ``990.0`` and ``32``; the lists here carry the same
+    types."""
     def is_int(x):
         return isinstance(x, (int, np.integer)) and not isinstance(x, bool)
     thr_int, min_int, damp_int = is_int(base_kernel_threshold), is_int(min_kernel_threshold), is_int(base_dumping_factor)
@@ -60,7 +63,7 @@ def results_from_history(hist, base_kernel_threshold, min_kernel_threshold, base
         t = float(hist[k, _lib.H_KERNEL_THR])
         thresholds.append(int(t) if thr_int and t.is_integer() else t)
         d = float(hist[k, _lib.H_DAMPING])
-        if d != prev_damp:
+        if d < prev_damp:                                                # a halving: true division
             damp_int = False
         prev_damp = d
         dampings.append(int(d) if damp_int and d.is_integer() else d)

@@ -493,14 +493,18 @@ static int launch_stage2(picp_ctx* ctx, const double* u, const double* v, const 
 // on holds its own copy of the array until the process ends; its address on a device is looked up
 // once, when a ctx is created on that device (noalloc_bind), and that address -- never the
 // array's name, which in host code is only a handle for the lookup -- is what kernels receive.
-constexpr int NOALLOC_MAX_WG = 512; // per-workgroup records of one scan that fit the array
+// Per-workgroup records of one scan that fit the array: the largest grids picp_create can configure on a
+// 256-CU device (8 workgroups per CU for stage 1, 4 for stage 2), so that the grids -- and with them the
+// order of additions -- are picp_linearize's whatever the tuning.
+constexpr int NOALLOC_MAX_WG1 = 2048;
+constexpr int NOALLOC_MAX_WG2 = 1024;
 enum : int {
     NA_STATE = 0,                                      // PICP_STATE_DOUBLES
     NA_S1 = 128,                                       // folded stage-1 record
     NA_S2 = 160,                                       // folded stage-2 record
-    NA_PART1 = 256,                                    // [NOALLOC_MAX_WG][PICP_S1_DOUBLES]
-    NA_PART2 = NA_PART1 + NOALLOC_MAX_WG * PICP_S1_DOUBLES, // [NOALLOC_MAX_WG][PICP_S2_DOUBLES]
-    NA_DOUBLES = NA_PART2 + NOALLOC_MAX_WG * PICP_S2_DOUBLES, // 18 688 doubles = 146 KiB per GPU
+    NA_PART1 = 256,                                    // [NOALLOC_MAX_WG1][PICP_S1_DOUBLES]
+    NA_PART2 = NA_PART1 + NOALLOC_MAX_WG1 * PICP_S1_DOUBLES, // [NOALLOC_MAX_WG2][PICP_S2_DOUBLES]
+    NA_DOUBLES = NA_PART2 + NOALLOC_MAX_WG2 * PICP_S2_DOUBLES, // 41 216 doubles = 322 KiB per GPU
 };
 static __device__ __align__(256) double scratch[NA_DOUBLES];
 
@@ -1050,8 +1054,8 @@ int picp_linearize_noalloc(picp_ctx* ctx, const double* u, const double* v, cons
     double* part2 = ws + NA_PART2;
     if (int rc = picp_state_init(ctx, state, w_T_c0_host, &sc)) return rc; // pose travels as a kernel argument
     DeviceGuard g(ctx->device);
-    const int cap1 = ctx->max_blocks1 < NOALLOC_MAX_WG ? ctx->max_blocks1 : NOALLOC_MAX_WG;
-    const int cap2 = ctx->max_blocks2 < NOALLOC_MAX_WG ? ctx->max_blocks2 : NOALLOC_MAX_WG;
+    const int cap1 = ctx->max_blocks1 < NOALLOC_MAX_WG1 ? ctx->max_blocks1 : NOALLOC_MAX_WG1;
+    const int cap2 = ctx->max_blocks2 < NOALLOC_MAX_WG2 ? ctx->max_blocks2 : NOALLOC_MAX_WG2;
     int rows1 = 0, rows2 = 0;
     if (int rc = launch_stage1(ctx, u, v, x, y, z, M, state, cam, part1, cap1, &rows1)) return rc;
     hipLaunchKernelGGL(fold_kernel<PICP_S1_DOUBLES>, dim3(1), dim3(NT), 0, ctx->stream, (const double*)part1, rows1,

@@ -79,3 +79,9 @@ def transform(poses, T=None, scale=1, are_points=False):
 def poses2positions(poses):
     """src/geometry_utils.py:111-115."""
     return [np.asarray(p)[:3, 3] for p in poses]
+
+
+# src/geometry_utils.py:64-91 is reachable from this module in the reference (its ProjectiveICP takes it from
+# `from src.geometry_utils import *`, src/ProjectiveICP.py:2, used at :74 and :109).  The DLT itself lives in
+# two_view.py, where it replaces cv2.triangulatePoints.
+from .two_view import triangulate_points  # noqa: E402,F401

@@ -100,12 +100,8 @@ class HipStages:
         return bool(self._host_state[_lib.ST_STOP] != 0.0)
 
     def state_checksum(self):
-        """62-bit checksum of the replicated state block's bit patterns (a one-ulp difference in any of
-        its 96 doubles changes it), for `check_replicas`."""
-        import torch
-        bits = self.state.view(torch.int64)
-        weights = torch.arange(1, 2 * bits.numel(), 2, dtype=torch.int64, device=bits.device)
-        return int((bits * weights).sum().item()) & ((1 << 62) - 1)
+        """62-bit checksum of the replicated state block (see `state_checksum`), for `check_replicas`."""
+        return state_checksum(self.state)
 
     def finish(self):
         res = _lib.ResultStruct()
@@ -206,6 +202,32 @@ def shutdown_peer_exchange(ctx, group=None):
     check(ctx.lib.picp_peer_destroy(ctx.handle), "picp_peer_destroy")
 
 
+def run_peer(ctx, corr, w_T_c0, cam, sched, want_history=True, group=None, fallback=True):
+    """`Context.run_sharded` with the outcome AGREED between the ranks before anyone acts on it.
+
+    picp_run_sharded reports per rank: one rank can give up at the last exchange after it has published its
+    own record, while a later rank finds every record present and returns success.  A caller that fell back
+    on the failing rank alone would then enter a collective the others never join.  Here every rank learns
+    whether all succeeded (one small all-gather per loop); if not, all of them tear the exchange down and --
+    with ``fallback`` -- run the same loop through the stage launches with the process group's all-reduces
+    (`run_sharded`), so every rank returns the same result either way.  Returns (result, history, used_peer)."""
+    res = hist = None
+    ok = True
+    try:
+        res, hist = ctx.run_sharded(corr, w_T_c0, cam, sched, want_history=want_history)
+    except _lib.PicpError:
+        ok = False
+    if _agree(ok, group):
+        return res, hist, True
+    shutdown_peer_exchange(ctx, group)
+    if not fallback:
+        raise _lib.PicpRetry("the in-kernel exchange failed on at least one rank; it has been shut down on all")
+    stages = HipStages(ctx, corr, w_T_c0, cam, sched, want_history=want_history)
+    res, hist = run_sharded(stages, int(sched.num_iterations), group=group, disable_stop=bool(sched.disable_stop),
+                            native=False)
+    return res, hist, False
+
+
 def _agree(ok, group=None):
     """Logical AND of ``ok`` over the ranks (all ranks get the same answer)."""
     import torch.distributed as dist
@@ -214,6 +236,33 @@ def _agree(ok, group=None):
     flags = [None] * dist.get_world_size(group)
     dist.all_gather_object(flags, bool(ok), group=group)
     return all(flags)
+
+
+def state_checksum(state):
+    """62-bit checksum of the bit patterns of a loop state block (device tensor of 96 doubles): a one-ulp
+    difference in any entry changes it."""
+    import torch
+    bits = state.view(torch.int64)
+    weights = torch.arange(1, 2 * bits.numel(), 2, dtype=torch.int64, device=bits.device)
+    return int((bits * weights).sum().item()) & ((1 << 62) - 1)
+
+
+def replicas_identical(state, group=None):
+    """Collective.  Compares the ranks' copies of the replicated loop state ``state`` (device tensor of 96
+    doubles, e.g. the block a `picp_run_sharded` call left behind) bit for bit through their checksums: one
+    all-reduce (MAX) of [c, -c], i.e. the maximum and the minimum over the ranks.  Returns
+    (identical, lowest checksum, highest checksum), the same on every rank.  A store between GPUs that did
+    not become visible, or one rank's sums differing in the last bit, shows here as False."""
+    import torch
+    import torch.distributed as dist
+    c = state_checksum(state)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return True, c, c
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.tensor([c, -c], dtype=torch.int64, device=state.device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0].item()), -int(t[1].item())
+    return hi == lo, lo, hi
 
 
 def check_replicas(stages, group=None):
@@ -233,7 +282,8 @@ def check_replicas(stages, group=None):
         return
     c = int(stages.state_checksum())
     on_gpu = dist.get_backend(group) == "nccl"
-    t = torch.tensor([c, -c], dtype=torch.int64, device=stages.state.device if on_gpu else "cpu")
+    device = stages.state.device if (on_gpu and hasattr(stages, "state")) else "cpu"
+    t = torch.tensor([c, -c], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     hi, lo = int(t[0].item()), -int(t[1].item())
     if hi != lo:

@@ -252,3 +252,28 @@ def test_frame_summary_text_and_number_types_match_the_reference():
         lines = "\n".join(P.summary_lines(res, True, lo, hi)).split("\n")
         start = want.index(lines[0])
         assert want[start:start + len(lines)] == lines, (c, want[start:start + len(lines)], lines)
+
+
+def test_damping_keeps_its_integer_type_through_doublings():
+    """`dumping_factor *= 2` on a Python int stays an int, only `/= 2` makes a float
+    (src/ProjectiveICP.py:224-225).  With the base damping at its minimum the first change is a doubling:
+    the reference's list then reads 1, 2, 4 (ints) and turns to floats at the first halving, for good."""
+    import importlib
+    P = importlib.import_module("monocular-visual-odometry_amd.ProjectiveICP")
+    L = importlib.import_module("monocular-visual-odometry_amd._lib")
+    seq = [1, 1, 2, 4, 4, 2, 4, 4]
+    want = []
+    d = 1                                     # the two statements of :224-225 on Python numbers
+    for k in range(1, len(seq)):
+        if seq[k] < seq[k - 1]:
+            d /= 2
+        elif seq[k] > seq[k - 1]:
+            d *= 2
+        want.append(d)
+    hist = np.zeros((len(seq) - 1, L.HIST_STRIDE))
+    hist[:, L.H_DAMPING] = seq[1:]
+    hist[:, L.H_KERNEL_THR] = 1000
+    hist[:, L.H_N_INSIDE] = 5
+    got = P.results_from_history(hist, 1000, 10, 1)["dumping_factor"]
+    assert got == want and [type(a) for a in got] == [type(b) for b in want], (got, want)
+    assert [type(a) for a in got] == [int, int, int, int, float, float, float]
