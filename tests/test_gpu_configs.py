@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import picp_oracle as po
+from oracle import picp_oracle_c as oc
 from tests.helpers import rel_err
 from tests.synthetic import TRUE_V, make_problem
 
@@ -21,8 +22,10 @@ def _cam_sched(num_iterations=20, disable_stop=True):
 
 def test_batched_4096_frames_of_2048_correspondences():
     """Config 3: 4 096 independent problems x 2 048 correspondences, each with its own true pose (seed =
-    frame id), one workgroup per problem.  A sample of problems is compared with the oracle; every
-    problem must converge to its own true pose; a problem's result must not depend on its neighbours."""
+    frame id), one workgroup per problem (8 correspondences per thread, the instantiation the benchmark
+    runs).  Every one of the 4 096 problems is compared with the C restatement of the reference loop,
+    iteration by iteration; every problem must converge to its own true pose; a problem's result must
+    not depend on its neighbours."""
     ctx = pkg.get_context(0)
     B, N = 4096, 2048
     rng = np.random.default_rng(123)
@@ -37,19 +40,34 @@ def test_batched_4096_frames_of_2048_correspondences():
     corr = ctx.soa(uv, pw)
     offsets = ctx.to_device(np.arange(B + 1, dtype=np.int64) * N, np.int64)
     poses0 = ctx.to_device(np.tile(np.eye(4).reshape(1, 16), (B, 1)))
-    results, _ = ctx.run_batched(corr, offsets, poses0, cam, sched)
+    results, hist = ctx.run_batched(corr, offsets, poses0, cam, sched, want_history=True, max_count=N)
     r = ctx.decode_results(results.cpu().numpy())
+    hist = hist.cpu().numpy()                                        # [B, 20, HIST_STRIDE]
     assert r["valid"].all() and (r["num_iterations"] == 20).all()
     assert np.max(np.abs(r["T"] - T_true)) < 5e-3                  # converged to each problem's own pose
+    # the history-free launch (what the benchmark times) gives the same results, bit for bit
+    results_nh, _ = ctx.run_batched(corr, offsets, poses0, cam, sched, max_count=N)
+    assert np.array_equal(results_nh.cpu().numpy().view(np.int64), results.cpu().numpy().view(np.int64))
+    # EVERY problem against the C restatement of the reference loop: all integer results of all iterations
+    # exact (in-image counts, inlier counts, thresholds, damping), errors and poses of all iterations to 1e-9
+    oc.load()
     params = po.IcpParams(num_iterations=20, disable_stop=True)
-    for p in (0, 1, 777, 2048, 4095):
-        T_ref, valid_ref, h_ref = po.projective_icp(uv[p * N:(p + 1) * N], pw[p * N:(p + 1) * N], np.eye(4), params)
+    worst_pose = worst_err = 0.0
+    for p in range(B):
+        T_ref, valid_ref, h_ref, best_ref = oc.projective_icp(uv[p * N:(p + 1) * N], pw[p * N:(p + 1) * N], np.eye(4), params)
+        h = hist[p]
+        assert valid_ref and len(h_ref) == 20
+        for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_KERNEL_THR, L.H_DAMPING):
+            assert np.array_equal(h[:, col], h_ref[:, col]), (p, col, h[:, col], h_ref[:, col])
+        worst_err = max(worst_err, rel_err(h[:, L.H_ERROR], h_ref[:, L.H_ERROR]))
+        worst_pose = max(worst_pose, rel_err(h[:, L.H_T:L.H_T + 16], h_ref[:, L.H_T:L.H_T + 16]))
         # converged errors tie to rounding noise, so the first-minimum index may differ; the pose must be
-        # the oracle's pose at the index the device picked, and that index must be a minimum to 1e-9
+        # the restatement's pose at the index the device picked, and that index must be a minimum to 1e-9
         k = int(r["best_index"][p])
-        assert abs(h_ref["error"][k] - h_ref["error"][h_ref["best_index"]]) <= 1e-9 * h_ref["error"][k]
-        assert rel_err(r["T"][p], h_ref["T"][k]) < 1e-9
-        assert abs(r["best_error"][p] - h_ref["error"][k]) <= 1e-9 * r["best_error"][p]
+        assert abs(h_ref[k, L.H_ERROR] - h_ref[best_ref, L.H_ERROR]) <= 1e-9 * h_ref[k, L.H_ERROR], p
+        assert rel_err(r["T"][p], h_ref[k, L.H_T:L.H_T + 16].reshape(4, 4)) < 1e-9, p
+        assert abs(r["best_error"][p] - h_ref[k, L.H_ERROR]) <= 1e-9 * r["best_error"][p], p
+    assert worst_err < 1e-9 and worst_pose < 1e-9, (worst_err, worst_pose)
     # isolation: the same problem alone gives bit-identical output
     for p in (5, 4000):
         sub = [c[p * N:(p + 1) * N] for c in corr]

@@ -21,16 +21,18 @@ def test_bundled_sequence_against_published_outputs(tmp_path):
     summary, r, vo = run_sequence.run(str(tmp_path), quiet=True)
     assert summary["frames"] == 120                                   # no frame rejected (published: 120 rows)
     assert summary["map_points"] == 395 and summary["map_appearances_identical"]
-    assert abs(summary["scale"] - summary["published_scale"]) < 1e-7
-    assert summary["max_trajectory_position_diff"] < 1e-4          # metres, over a ~25 m path (observed 1e-5)
-    assert summary["max_world_point_diff"] < 1e-3                  # observed 1e-4 on the farthest points
-    assert summary["max_abs_rotation_ratio_diff"] < 1e-5
-    assert summary["max_abs_rotation_error_diff"] < 1e-9           # errors.dat column 2 (rounded rotations, :124)
-    assert summary["max_abs_translation_error_diff"] < 1e-4        # column 4
-    assert summary["max_abs_translation_ratio_diff"] < 1e-6        # column 5
+    # twice what is observed (in brackets); tests/test_oracle_sequence.py shows where that distance comes from: the
+    # sequence amplifies the 3e-10 by which the two-view bootstrap here differs from OpenCV's
+    assert abs(summary["scale"] - summary["published_scale"]) < 1e-8   # (2.6e-9)
+    assert summary["max_trajectory_position_diff"] < 2e-5          # metres, over a ~25 m path (9.4e-6, at pose 71)
+    assert summary["max_world_point_diff"] < 1.2e-4                # (5.7e-5, on the farthest points)
+    assert summary["max_abs_rotation_ratio_diff"] < 9e-7           # errors.dat column 3 (4.4e-7)
+    assert summary["max_abs_rotation_error_diff"] < 1e-12          # column 2 (rounded rotations, :124) (1.4e-17)
+    assert summary["max_abs_translation_error_diff"] < 2.7e-5      # column 4 (1.3e-5)
+    assert summary["max_abs_translation_ratio_diff"] < 1e-7        # column 5 (4.7e-8)
     pub = load_golden("bundled_sequence.npz")["published_errors"]
     rot = np.nan_to_num(np.array(r["rotation_error"]))
-    assert np.max(np.abs(rot - pub[:, 1])) < 1e-9
+    assert np.max(np.abs(rot - pub[:, 1])) < 1e-12
     # written files parse back to what was computed
     err = np.loadtxt(tmp_path / "outputs" / "final_results" / "errors.dat")
     assert err.shape == (120, 5) and np.allclose(np.nan_to_num(err[:, 1]), rot)

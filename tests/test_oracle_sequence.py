@@ -19,7 +19,9 @@ def _frame(b, f):
     return b["meas_uv"][mo[f]:mo[f + 1]], b["meas_app"][mo[f]:mo[f + 1]]
 
 
-def _run_sequence_with_the_oracle(b, frames=120):
+def _run_sequence_with_the_oracle(b, frames=120, bootstrap_shift=None, watch=None):
+    """bootstrap_shift: added to the translation of the two-view bootstrap pose (sensitivity runs).
+    watch(frame, history): called with every frame's iteration history."""
     tv = pkg.two_view
     K = b["camera_matrix"].astype(np.float64)
     params = po.IcpParams()                                   # config/config.yaml:11-22
@@ -39,6 +41,8 @@ def _run_sequence_with_the_oracle(b, frames=120):
     E, mask = tv.find_essential_mat(p0, p1, K)
     R, t, mask = tv.recover_pose(E, p0, p1, K, mask)
     pose = pkg.geometry_utils.Rt2T(R, -t)
+    if bootstrap_shift is not None:
+        pose[:3, 3] += bootstrap_shift
     traj += [np.eye(4), pose]
     pts, m = tv.triangulate_points(p0, p1, np.eye(4), pose, K)
     add_to_map(pts, a0[i0][m])
@@ -49,6 +53,8 @@ def _run_sequence_with_the_oracle(b, frames=120):
         T, valid, hist = po.projective_icp(un[j1], np.array(map_pos)[j2], pose, params)
         iterations += len(hist["error"])
         assert valid, f
+        if watch is not None:
+            watch(f, hist)
         i0, i1 = po.associate(ac, an)
         pts, m = tv.triangulate_points(uc[i0], un[i1], pose, T, K)
         add_to_map(pts, ac[i0][m])
@@ -65,17 +71,77 @@ def test_oracle_driven_sequence_reproduces_the_published_outputs():
     r = pkg.evaluation.trajectory_errors(traj, world, gt, b["cam_transform"], 0)
     pub_err, pub_traj, pub_pts = b["published_errors"], b["published_trajectory"], b["published_world_points"]
     assert len(r["rotation_error"]) == len(pub_err) == 120
-    assert abs(r["scale"] - np.mean(pub_err[:, 4])) < 1e-7
+    # thresholds: twice what is observed (in brackets); the next test shows where the distance comes from
+    assert abs(r["scale"] - np.mean(pub_err[:, 4])) < 1e-8                                   # (2.5e-9)
     # estimated_trajectory.dat: id x y z
     est = np.array([p[:3, 3] for p in r["trajectory"]])
-    assert np.abs(est - pub_traj[:, 1:4]).max() < 1e-4        # metres over ~25 m; typically 1e-9 .. 1e-6
-    assert np.median(np.abs(est - pub_traj[:, 1:4]).max(axis=1)) < 1e-6
+    assert np.abs(est - pub_traj[:, 1:4]).max() < 2e-5        # metres over ~25 m (9.3e-6, at pose 71)
+    assert np.median(np.abs(est - pub_traj[:, 1:4]).max(axis=1)) < 4e-7                      # (1.7e-7)
     # estimated_world_points.dat: id x y z appearance, in insertion order
     assert len(world["position"]) == len(pub_pts) == 395
     assert np.array_equal(np.array(world["appearance"]), pub_pts[:, 4:])
-    assert np.abs(np.array(r["world_points"]) - pub_pts[:, 1:4]).max() < 1e-3
+    assert np.abs(np.array(r["world_points"]) - pub_pts[:, 1:4]).max() < 1.2e-4              # (5.7e-5)
     # errors.dat: id rotation_error rotation_ratio translation_error translation_ratio
-    assert np.abs(np.nan_to_num(np.array(r["rotation_error"])) - pub_err[:, 1]).max() < 1e-9
-    assert np.abs(np.array(r["rotation_ratio"]) - pub_err[:, 2]).max() < 1e-5
-    assert np.abs(np.array(r["translation_error"])[1:] - pub_err[1:, 3]).max() < 1e-4
-    assert np.abs(np.array(r["translation_ratio"])[1:] - pub_err[1:, 4]).max() < 1e-6
+    assert np.abs(np.nan_to_num(np.array(r["rotation_error"])) - pub_err[:, 1]).max() < 1e-12   # (1.4e-17)
+    assert np.abs(np.array(r["rotation_ratio"]) - pub_err[:, 2]).max() < 9e-7                # (4.4e-7)
+    assert np.abs(np.array(r["translation_error"])[1:] - pub_err[1:, 3]).max() < 2.7e-5      # (1.3e-5)
+    assert np.abs(np.array(r["translation_ratio"])[1:] - pub_err[1:, 4]).max() < 1e-7        # (4.7e-8)
+
+def _published_camera_positions(b):
+    """The camera positions of the published run in the first camera's frame, recovered from
+    estimated_trajectory.dat: its rows are scale * (R_C t + t_C) with [R_C | t_C] the camera's pose on the
+    robot (src/VisualOdometry.py:104-107, :156), and row 0 (t = 0) gives the scale."""
+    C, pub = b["cam_transform"], b["published_trajectory"]
+    scale = pub[0, 1:4] @ C[:3, 3] / (C[:3, 3] @ C[:3, 3])
+    return (pub[:, 1:4] / scale - C[:3, 3]) @ C[:3, :3]
+
+
+def test_what_separates_the_run_from_the_published_one():
+    """Where the remaining distance to the published trajectory (up to 5e-5 camera units on one frame,
+    1e-6 typically) comes from.
+
+    (1) NOT from `argmin(error)` (src/ProjectiveICP.py:249) choosing between iterations whose errors tie:
+    on the turning frames a hundred iterations tie to 1e-9 of the minimum, but no tied iteration's pose is
+    closer to the published row than the chosen one's by more than a few percent (the tied poses lie within
+    2e-7 of each other, mostly within 1e-8), so a differently rounded run that picked another of them
+    would be just as far away.
+    (2) From the sequence's own sensitivity.  The two-view bootstrap here differs from OpenCV's by 3e-10
+    (different five-point / SVD arithmetic); every later pose is computed from map points triangulated
+    with earlier poses, and the chain amplifies such a difference.  Shifting the bootstrap translation by
+    3e-10 in a random direction moves the trajectory, frame by frame, by as much as the published run is
+    away from it: the same growth along the sequence and the same spike at pose 71 (a frame whose loop
+    runs all 250 iterations without converging, error 3.4), which is an order of magnitude more
+    sensitive than its neighbours."""
+    b = load()
+    t_pub = _published_camera_positions(b)
+    tied_frames, gain, spread = [], [0.0], [0.0]
+
+    def ties_do_not_explain(f, hist):
+        err = np.array(hist["error"])
+        k = int(np.argmin(err))
+        tied = np.flatnonzero(np.abs(err - err[k]) <= 1e-9 * err[k])
+        if len(tied) > 1:
+            t = np.array([hist["T"][q][:3, 3] for q in tied])
+            chosen = np.abs(hist["T"][k][:3, 3] - t_pub[f + 1]).max()
+            closest = np.abs(t - t_pub[f + 1]).max(axis=1).min()
+            gain[0] = max(gain[0], (chosen - closest) / chosen)
+            spread[0] = max(spread[0], np.abs(t - hist["T"][k][:3, 3]).max())
+            tied_frames.append(f)
+
+    traj, _, _ = _run_sequence_with_the_oracle(b, watch=ties_do_not_explain)
+    base = np.array([p[:3, 3] for p in traj])
+    assert len(tied_frames) > 50                                  # the turns: ties are the rule there
+    assert gain[0] < 0.1 and spread[0] < 1e-6, (gain, spread)     # observed 0.04 and 2.0e-7
+    to_published = np.abs(base - t_pub).max(axis=1)
+    assert to_published[1] < 1e-9                                 # the bootstrap itself (observed 2.7e-10)
+    moved = np.zeros(len(base))
+    for seed in (1, 2):
+        shift = 3e-10 * np.random.default_rng(seed).standard_normal(3)
+        t2, _, _ = _run_sequence_with_the_oracle(b, bootstrap_shift=shift)
+        moved = np.maximum(moved, np.abs(np.array([p[:3, 3] for p in t2]) - base).max(axis=1))
+    assert moved.max() > 3e-6 and int(np.argmax(moved)) == int(np.argmax(to_published)) == 71
+    # frame by frame the published run is no farther away than a small multiple of what the 3e-10 shift does
+    ratio = to_published[2:] / (moved[2:] + 1e-12)
+    assert np.all(to_published[2:] <= 25 * moved[2:] + 1e-9), ratio.max()
+    assert np.median(ratio) < 5, np.median(ratio)
+    assert to_published.max() < 6e-5 and np.median(to_published) < 2e-6
