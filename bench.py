@@ -237,13 +237,15 @@ def result_pose(res):
 
 
 # ---- sharded runs: choice of the exchange ------------------------------------------------------------
-def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
+def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages, stage_state):
     """Sets up the exchange between the ranks and returns (mode, description).  Every decision is taken
     collectively (all ranks end on the same path).  The reference is the stage-launch loop with
     torch.distributed's own all-reduce between the stages, which needs nothing from this library beyond
     its kernels.  The in-kernel exchange (all of its waits are bounded, so a failure ends in an error, not
-    in a hang) is tried first and used only after one trial loop through it has given the reference's
-    result; failing that, the library's own RCCL communicator is tried the same way."""
+    in a hang) is tried first and used only after twenty trial loops through it have each given the reference's
+    result and left bit-identical loop states on all ranks; failing that, the library's own RCCL communicator is
+    tried the same way.
+    stage_state(): the state block the stage-launch loops leave their final state in."""
     S = pkg.sharded
     want = os.environ.get("PICP_BENCH_EXCHANGE", "auto")   # auto | peer | rccl | torch
     rank = dist.get_rank()
@@ -265,18 +267,45 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
         torch.cuda.synchronize()
         return max_over_ranks((time.perf_counter() - t0) / n, world, backend) * 1e3
 
+    TRIAL_LOOPS = 20
+
+    def trial(fn, state_of, what):
+        """TRIAL_LOOPS loops through `fn`, each compared with the reference result and, bit for bit, between the
+        ranks (checksum of the 96-double loop state every rank is left with).  Collective; returns (ok, why) the
+        same on every rank.  A rank whose loop raises keeps taking part in the comparisons, so nobody waits alone."""
+        for k in range(TRIAL_LOOPS):
+            ok, why = True, ""
+            try:
+                got = fn()
+                if not same(got):
+                    ok, why = False, f"loop {k + 1} of its trial disagreed with the stage launches"
+                if os.environ.get("PICP_INJECT_FAILURE") == "trial_bits" and rank == world - 1 and k == 7:
+                    state_of()[5] += 1e-13                      # rehearsal: one rank's state differs in its last bits
+            except pkg._lib.PicpError as e:
+                ok, why = False, f"loop {k + 1} of its trial failed ({e})"
+            identical = True
+            if S._agree(ok):
+                identical, lo_c, hi_c = S.replicas_identical(state_of())
+                if not identical:
+                    why = (f"after loop {k + 1} of its trial the ranks' loop states differed (checksums {lo_c:#x} .. "
+                           f"{hi_c:#x})")
+            elif not why:
+                why = f"loop {k + 1} of its trial failed on another rank"
+            if not (ok and identical) or why:
+                if why:
+                    print(f"rank {rank}: {what} not used: {why}", file=sys.stderr)
+                return False, why or "its trial failed"
+        return True, ""
+
     notes = []
     if want in ("auto", "peer") and S.init_peer_exchange(ctx):
-        ok, why = True, ""
-        try:
-            if not same(step_peer()):
-                ok, why = False, "its trial loop disagreed with the stage launches"
-        except pkg._lib.PicpError as e:
-            ok, why = False, f"its trial loop failed ({e})"
-        if S._agree(ok):
+        ok, why = trial(step_peer, lambda: ctx._run_state, "in-kernel exchange")
+        if ok:
             # both paths work: keep the in-kernel exchange unless the stage launches are faster on this
             # machine (they are not where it was rehearsed; between real GPUs the peer stores are untried)
-            text = "in-kernel exchange through peer memory (HIP IPC, xGMI stores), one launch per loop"
+            text = (f"in-kernel exchange through peer memory (HIP IPC, xGMI stores into {S.peer_memory_kind(ctx)}), one "
+                    f"launch per loop; {TRIAL_LOOPS} trial loops equal to the stage launches' result and bit-identical "
+                    "between the ranks")
             if want == "peer":
                 return "peer", text, None
             try:
@@ -293,29 +322,29 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages):
             why = ("it failed while being timed" if failed else
                    f"the stage launches were faster in the trial ({ms_stages:.3f} ms per loop against {ms_peer:.3f} ms)")
             notes.append(f"the in-kernel exchange passed its trial but {why}")
-        else:
-            notes.append("the in-kernel exchange was set up but failed its trial")
-        if why:
             print(f"rank {rank}: in-kernel exchange not used: {why}", file=sys.stderr)
+        else:
+            notes.append(f"the in-kernel exchange was set up but failed its trial ({why})")
         S.shutdown_peer_exchange(ctx)
-    if want in ("auto", "rccl") and backend == "nccl" and S.init_native_exchange(ctx):
-        # one all-reduce of known values through the library's communicator, then a trial loop
+    elif want in ("auto", "peer"):
+        notes.append("the in-kernel exchange could not be set up (see stderr for the pair of GPUs)")
+    # (on gloo only for rehearsals of the set-up's failure paths: RCCL refuses two ranks on one device)
+    native_allowed = backend == "nccl" or want == "rccl" or os.environ.get("PICP_BENCH_NATIVE_ON_GLOO") == "1"
+    if want in ("auto", "rccl") and native_allowed and S.init_native_exchange(ctx):
+        # one all-reduce of known values through the library's communicator, then a trial
         probe = ctx.to_device(np.full(4, float(rank + 1)))
         ok = ctx.lib.picp_comm_allreduce(ctx.handle, ctx.ptr(probe), 4) == 0
         ctx.synchronize()
         ok = ok and bool(np.all(probe.cpu().numpy() == world * (world + 1) / 2))
         if S._agree(ok):
-            try:
-                ok = same(step_stages("rccl"))
-            except pkg._lib.PicpError as e:
-                print(f"rank {rank}: library all-reduce not used: {e}", file=sys.stderr)
-                ok = False
-            ok = S._agree(ok)
+            ok, why = trial(lambda: step_stages("rccl"), lambda: stage_state(), "library all-reduce")
         if ok:
             return "rccl", "; ".join(["rccl all-reduces enqueued by the library on the kernels' stream, two launches per "
-                                      "iteration"] + notes), None
+                                      f"iteration; {TRIAL_LOOPS} trial loops bit-identical between the ranks"] + notes), None
         S.shutdown_native_exchange(ctx)
         notes.append("the library's own RCCL communicator failed its trial")
+    elif want in ("auto", "rccl") and native_allowed:
+        notes.append("the library's own RCCL communicator could not be set up")
     return "torch", "; ".join([f"{backend} all-reduces through torch.distributed between stage launches"] + notes), None
 
 
@@ -430,7 +459,8 @@ def bench_loop(args):
     mode, collective, trial_ms = None, None, None
     if world > 1:
         ctx.lib.picp_set_launch_timing(ctx.handle, 1)
-        mode, collective, trial_ms = choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages)
+        mode, collective, trial_ms = choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages,
+                                                     lambda: stage_set[0].state)
 
     def step():
         if world == 1:

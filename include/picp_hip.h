@@ -279,6 +279,23 @@ int picp_peer_create(picp_ctx* ctx, int32_t rank, int32_t world, void* handle_ho
 int picp_peer_connect(picp_ctx* ctx, const void* handles_host);
 int picp_peer_destroy(picp_ctx* ctx);
 int picp_peer_world(picp_ctx* ctx);
+/* Checks to make BEFORE picp_peer_connect, so that a pair of GPUs without peer access ends in a message that
+ * names the pair (and in the callers' fallback) rather than in a failed mapping or a fault:
+ *   picp_device_bus_id    the PCI bus id of the ctx's GPU as a string (host, PICP_BUS_ID_BYTES bytes), for the
+ *                         caller to hand to every rank next to the IPC handle (device ordinals are per process);
+ *   picp_peer_can_access  *can = 1 when the ctx's GPU can map memory of the GPU with that bus id (or is that GPU),
+ *                         0 when it cannot, -1 when this process does not see that GPU and so cannot tell.
+ * picp_peer_memory_kind: how picp_peer_create got the exchange memory -- uncached device memory, or, where that
+ * is refused, fine-grained device memory (PICP_PEER_MEMORY_*; 0 without an exchange).  No counterpart in the reference. */
+#define PICP_BUS_ID_BYTES 64
+#define PICP_PEER_MEMORY_NONE 0
+#define PICP_PEER_MEMORY_UNCACHED 1
+#define PICP_PEER_MEMORY_FINEGRAINED 2
+int picp_device_bus_id(picp_ctx* ctx, char* bus_id_host, int64_t bytes);
+int picp_peer_can_access(picp_ctx* ctx, const char* peer_bus_id_host, int32_t* can);
+int picp_peer_memory_kind(picp_ctx* ctx);
+/* 1 when librccl can be loaded by this process (picp_comm_init would not fail for that reason), else 0. */
+int picp_comm_available(void);
 int picp_run_sharded(picp_ctx* ctx, const double* u, const double* v, const double* x, const double* y,
                      const double* z, int64_t M, const double* w_T_c0_host, const picp_camera* cam,
                      const picp_schedule* sched, double* state, double* hist, int32_t hist_rows,

@@ -40,6 +40,8 @@ ASYNC_SLOTS = 4
 COMM_ID_BYTES = 128
 PEER_MAX_RANKS = 8
 PEER_HANDLE_BYTES = 64
+BUS_ID_BYTES = 64
+PEER_MEMORY_KINDS = {0: "none", 1: "uncached device memory", 2: "fine-grained device memory"}
 
 
 class PicpError(RuntimeError):
@@ -113,6 +115,10 @@ _SIGNATURES = {
     "picp_peer_connect": (C.c_int, [_P, _P]),
     "picp_peer_destroy": (C.c_int, [_P]),
     "picp_peer_world": (C.c_int, [_P]),
+    "picp_device_bus_id": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "picp_peer_can_access": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
+    "picp_peer_memory_kind": (C.c_int, [_P]),
+    "picp_comm_available": (C.c_int, []),
     "picp_run_sharded": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
                                    C.POINTER(ScheduleStruct), _P, _P, C.c_int32, C.POINTER(ResultStruct)]),
     "picp_set_grid_limit": (C.c_int, [_P, C.c_int32]),

@@ -82,6 +82,8 @@ using namespace picp;
 
 extern "C" {
 
+int picp_comm_available(void) { return rccl() != nullptr ? 1 : 0; }
+
 int picp_comm_unique_id(void* id, int64_t bytes) {
     PICP_REQUIRE(id != nullptr && bytes >= PICP_COMM_ID_BYTES, "picp_comm_unique_id: needs a buffer of %d bytes",
                  PICP_COMM_ID_BYTES);

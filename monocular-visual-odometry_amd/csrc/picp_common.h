@@ -62,6 +62,7 @@ struct picp_ctx {
     int peer_rank, peer_world;     // peer_world == 0: not set up
     int peer_connected;            // the peers' memory is mapped
     int peer_broken;               // a launch gave up at an exchange: the slots are in an unknown state
+    int peer_memory_kind;          // how the exchange memory was allocated: 0 none, 1 uncached, 2 fine-grained
     unsigned peer_epoch;           // exchanges between the GPUs completed by earlier launches
     unsigned peer_spin_limit;      // polls before a workgroup waiting for a peer gives up
     int time_launches;             // picp_run_sharded brackets its launch with events (picp_set_launch_timing)

@@ -3,6 +3,8 @@
 // Every rank owns a few kilobytes of device memory that its peers write into while the loops run
 // (picp_resident.hip: cross_total).  It is allocated uncached, so that neither the writers' nor the
 // readers' L2 keeps a copy, and handed to the other processes as a HIP IPC handle.
+#include <stdlib.h>
+
 #include "picp_common.h"
 
 using namespace picp;
@@ -18,10 +20,16 @@ int picp_peer_create(picp_ctx* ctx, int32_t rank, int32_t world, void* handle_ho
     DeviceGuard g(ctx->device);
     double* own = nullptr;
     const size_t bytes = sizeof(double) * (size_t)peer_slot_doubles();
-    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&own), bytes, hipDeviceMallocUncached);
+    // PICP_PEER_MEMORY=finegrained skips the uncached attempt (to try the other flavour on a machine where both work)
+    const char* want = getenv("PICP_PEER_MEMORY");
+    const bool try_uncached = !(want && strcmp(want, "finegrained") == 0);
+    hipError_t e = try_uncached ? hipExtMallocWithFlags(reinterpret_cast<void**>(&own), bytes, hipDeviceMallocUncached)
+                                : hipErrorInvalidValue;
+    int kind = PICP_PEER_MEMORY_UNCACHED;
     if (e != hipSuccess) {
         (void)hipGetLastError();
         e = hipExtMallocWithFlags(reinterpret_cast<void**>(&own), bytes, hipDeviceMallocFinegrained);
+        kind = PICP_PEER_MEMORY_FINEGRAINED;
     }
     if (e != hipSuccess) return hip_fail(e, "picp_peer_create: allocation of the exchange memory");
     peer_fill(ctx, own);
@@ -41,6 +49,38 @@ int picp_peer_create(picp_ctx* ctx, int32_t rank, int32_t world, void* handle_ho
     ctx->peer_connected = (world == 1);
     ctx->peer_broken = 0;
     ctx->peer_epoch = 0;
+    ctx->peer_memory_kind = kind;
+    return PICP_OK;
+}
+
+int picp_peer_memory_kind(picp_ctx* ctx) { return (ctx && ctx->peer_world >= 1) ? ctx->peer_memory_kind : PICP_PEER_MEMORY_NONE; }
+
+int picp_device_bus_id(picp_ctx* ctx, char* out, int64_t bytes) {
+    PICP_REQUIRE(ctx != nullptr && out != nullptr && bytes >= PICP_BUS_ID_BYTES, "picp_device_bus_id: needs a buffer of %d bytes",
+                 PICP_BUS_ID_BYTES);
+    memset(out, 0, (size_t)bytes);
+    PICP_HIP_CHECK(hipDeviceGetPCIBusId(out, (int)bytes, ctx->device));
+    return PICP_OK;
+}
+
+int picp_peer_can_access(picp_ctx* ctx, const char* peer_bus_id, int32_t* can) {
+    PICP_REQUIRE(ctx != nullptr && peer_bus_id != nullptr && can != nullptr, "picp_peer_can_access: null argument");
+    *can = -1;
+    int peer = -1;
+    if (hipDeviceGetByPCIBusId(&peer, peer_bus_id) != hipSuccess) { // the peer's GPU is not visible to this process
+        (void)hipGetLastError();
+        return PICP_OK;
+    }
+    if (peer == ctx->device) { // ranks sharing one GPU (rehearsals): its own memory
+        *can = 1;
+        return PICP_OK;
+    }
+    int yes = 0;
+    if (hipDeviceCanAccessPeer(&yes, ctx->device, peer) != hipSuccess) {
+        (void)hipGetLastError();
+        return PICP_OK;
+    }
+    *can = yes ? 1 : 0;
     return PICP_OK;
 }
 
@@ -85,6 +125,7 @@ int picp_peer_destroy(picp_ctx* ctx) {
     ctx->peer_connected = 0;
     ctx->peer_broken = 0;
     ctx->peer_epoch = 0;
+    ctx->peer_memory_kind = PICP_PEER_MEMORY_NONE;
     return PICP_OK;
 }
 

@@ -124,12 +124,35 @@ class HipStages:
         return res, hist
 
 
-def init_native_exchange(ctx, group=None):
+def _injected(what):
+    """Failure injection for rehearsals (PICP_INJECT_FAILURE=<what>[,<what>...]): the LAST rank pretends that
+    step failed, so that the collective fallbacks can be exercised on a healthy machine."""
+    import os
+    import torch.distributed as dist
+    if what not in os.environ.get("PICP_INJECT_FAILURE", "").split(","):
+        return False
+    multi = dist.is_available() and dist.is_initialized()
+    return (not multi) or dist.get_rank() == dist.get_world_size() - 1
+
+
+COMM_INIT_TIMEOUT_S = 120.0
+
+
+def init_native_exchange(ctx, group=None, timeout_s=None):
     """Gives ``ctx`` an RCCL communicator over the ranks of ``group`` (default: the world), for
     `HipStages.rounds`.  The id RCCL needs is made on rank 0 and handed round through the existing
     process group, whatever its backend.  Collective: every rank must call it.  Returns True when all
     ranks have their communicator; otherwise every rank is left without one (and the generic
-    exchange is used)."""
+    exchange is used).
+
+    ncclCommInitRank blocks until every rank has joined, so a rank that cannot join must be known
+    BEFORE anyone calls it: the ranks first agree, through the process group, that each of them can load
+    RCCL and holds the id.  The call itself then runs in a helper thread and is given ``timeout_s``
+    (default COMM_INIT_TIMEOUT_S, or PICP_COMM_INIT_TIMEOUT): a rank whose peers never arrive reports
+    failure instead of waiting for ever (its helper thread stays blocked; the process goes on without
+    a communicator)."""
+    import os
+    import threading
     import torch
     import torch.distributed as dist
     lib = ctx.lib
@@ -145,15 +168,30 @@ def init_native_exchange(ctx, group=None):
             box[0] = bytes(buf.raw)
     if world > 1:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    if box[0] is None:
+    ready = box[0] is not None and int(lib.picp_comm_available()) == 1 and not _injected("comm_ready")
+    if not _agree(ready, group):                       # nobody enters ncclCommInitRank unless everybody will
         return False
-    ok = lib.picp_comm_init(ctx.handle, box[0], rank, world) == _lib.PICP_OK
-    if world > 1:
-        on_gpu = dist.get_backend(group) == "nccl"
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctx.device if on_gpu else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        ok = bool(flag.item())
-    if not ok:
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("PICP_COMM_INIT_TIMEOUT", COMM_INIT_TIMEOUT_S))
+    done = {}
+
+    def join():
+        done["rc"] = lib.picp_comm_init(ctx.handle, box[0], rank, world)
+
+    if _injected("comm_init"):
+        ok = False                                     # this rank never joins: the others run into their time limit
+    else:
+        t = threading.Thread(target=join, daemon=True)
+        t.start()
+        t.join(timeout_s)
+        ok = (not t.is_alive()) and done.get("rc") == _lib.PICP_OK
+        if t.is_alive():
+            import sys
+            print(f"rank {rank}: picp_comm_init did not return within {timeout_s:.0f} s (a rank never joined); "
+                  "going on without the library's communicator", file=sys.stderr)
+            ctx._comm_init_stuck = True                # the communicator may still appear later: never use or destroy it
+    ok = _agree(ok, group)
+    if not ok and not getattr(ctx, "_comm_init_stuck", False):
         lib.picp_comm_destroy(ctx.handle)
     return ok
 
@@ -167,9 +205,13 @@ def shutdown_native_exchange(ctx):
 def init_peer_exchange(ctx, group=None):
     """Sets up the in-kernel exchange between the GPUs of ``group`` (default: the world) on ``ctx``: every
     rank allocates its exchange memory, the HIP IPC handles travel through the existing process group
-    (whatever its backend), every rank maps its peers' memory.  Collective: every rank must call it.
-    Returns True when every rank is connected; otherwise every rank is left without an exchange (and
-    `run_sharded` / `picp_sharded_rounds` are used).  At most PEER_MAX_RANKS ranks, one node."""
+    (whatever its backend) together with each GPU's PCI bus id and the host's name, every rank checks that
+    its GPU can map every peer's memory (same host, peer access between the two GPUs) and only then maps it.
+    Collective: every rank must call it.  Returns True when every rank is connected; otherwise every rank is
+    left without an exchange (and `run_sharded` / `picp_sharded_rounds` are used), and the rank that found
+    the obstacle says on stderr which pair of GPUs it was.  At most PEER_MAX_RANKS ranks, one node."""
+    import socket
+    import sys
     import torch.distributed as dist
     lib = ctx.lib
     if int(lib.picp_peer_world(ctx.handle)) >= 1:
@@ -179,19 +221,47 @@ def init_peer_exchange(ctx, group=None):
     world = dist.get_world_size(group) if multi else 1
     ok = world <= _lib.PEER_MAX_RANKS
     buf = C.create_string_buffer(_lib.PEER_HANDLE_BYTES)
-    ok = ok and lib.picp_peer_create(ctx.handle, rank, world, buf) == _lib.PICP_OK
-    handles = [bytes(buf.raw) if ok else None]
+    ok = ok and not _injected("peer_create") and lib.picp_peer_create(ctx.handle, rank, world, buf) == _lib.PICP_OK
+    bus = C.create_string_buffer(_lib.BUS_ID_BYTES)
+    bus_id = bus.value if lib.picp_device_bus_id(ctx.handle, bus, _lib.BUS_ID_BYTES) == _lib.PICP_OK else b""
+    mine = (bytes(buf.raw) if ok else None, bus_id, socket.gethostname())
+    everyone = [mine]
     if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, handles[0], group=group)      # also: every rank is past its create
-        handles = gathered
-    ok = all(h is not None for h in handles)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=group)           # also: every rank is past its create
+    ok = all(h is not None for h, _, _ in everyone)
     if ok and world > 1:
-        ok = lib.picp_peer_connect(ctx.handle, b"".join(handles)) == _lib.PICP_OK
-    ok = _agree(ok, group)                                              # also: every rank is past its connect
+        for peer, (_, peer_bus, peer_host) in enumerate(everyone):
+            if peer == rank:
+                continue
+            can = C.c_int32(-1)
+            if peer_host != mine[2]:
+                can.value = 0
+                why = f"it is on another host ({peer_host!r}, this rank on {mine[2]!r}): the exchange works inside one node"
+            else:
+                lib.picp_peer_can_access(ctx.handle, peer_bus, C.byref(can))
+                why = "hipDeviceCanAccessPeer says no"
+            if _injected("peer_access") and peer == 0:
+                can.value, why = 0, "injected failure (PICP_INJECT_FAILURE=peer_access)"
+            if can.value == 0:                                        # -1: not visible from here; the mapping will tell
+                print(f"rank {rank} (GPU {bus_id.decode() or '?'}) cannot map the exchange memory of rank {peer} "
+                      f"(GPU {peer_bus.decode() or '?'}): {why}", file=sys.stderr)
+                ok = False
+    ok = _agree(ok, group)                                              # nobody maps anything unless every pair is fine
+    if ok and world > 1:
+        ok = lib.picp_peer_connect(ctx.handle, b"".join(h for h, _, _ in everyone)) == _lib.PICP_OK
+        if not ok:
+            print(f"rank {rank}: {lib.picp_last_error().decode()}", file=sys.stderr)
+        ok = _agree(ok, group)                                          # also: every rank is past its connect
     if not ok:
         lib.picp_peer_destroy(ctx.handle)
     return ok
+
+
+def peer_memory_kind(ctx):
+    """How the ctx's exchange memory was allocated ("uncached device memory", or "fine-grained device memory"
+    where the former is refused; "none" without an exchange)."""
+    return _lib.PEER_MEMORY_KINDS.get(int(ctx.lib.picp_peer_memory_kind(ctx.handle)), "unknown")
 
 
 def shutdown_peer_exchange(ctx, group=None):

@@ -68,7 +68,7 @@ def check_history(hist, g, pre, lo=None, hi=None):
     e = hist[:, L.H_ERROR]
     assert np.array_equal(np.isinf(e), np.isinf(e_ref))
     fin = np.isfinite(e_ref)
-    assert np.all(np.abs(e[fin] - e_ref[fin]) <= 1e-8 * np.abs(e_ref[fin]) + 1e-18)
+    assert np.all(np.abs(e[fin] - e_ref[fin]) <= 1e-9 * np.abs(e_ref[fin]) + 1e-18)
     assert rel_err(hist[:, L.H_T:L.H_T + 16].reshape(-1, 4, 4), g[f"{pre}T"][sl]) < TOL
     Href, bref, dxref = g[f"{pre}H"][sl], g[f"{pre}b"][sl], g[f"{pre}dx"][sl]
     for k in range(hist.shape[0]):
@@ -80,7 +80,7 @@ def check_history(hist, g, pre, lo=None, hi=None):
         if np.max(np.abs(dxref[k])) > 0:
             # dx = -(H + lambda I)^-1 b inherits b's cancellation noise once the loop has converged,
             # hence the absolute term (poses are O(1), so 1e-12 is far inside the 1e-9 pose bar)
-            assert np.max(np.abs(hist[k, L.H_DX:L.H_DX + 6] - dxref[k])) <= 1e-8 * np.max(np.abs(dxref[k])) + 1e-12, k
+            assert np.max(np.abs(hist[k, L.H_DX:L.H_DX + 6] - dxref[k])) <= TOL * np.max(np.abs(dxref[k])) + 1e-12, k
 
 
 def check_best(T, best_index, e_ref, T_ref_hist, T_out_ref):
