@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=["loop", "batched", "assoc"], default="loop")
     ap.add_argument("--corr", type=int, default=0, help="total correspondences (default 2^20 at 1 GPU, 2^26 sharded)")
+    ap.add_argument("--method", choices=["hash", "scan"], default="hash",
+                    help="--config assoc: which of picp_associate's two methods the line's value reports (hash: the "
+                         "join it picks at this size; scan: the all-pairs test, the reference's double loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-scan", action="store_true", help="skip the 2^24-correspondence stage-2 timing")
     ap.add_argument("--no-single-gpu", action="store_true",
@@ -882,6 +885,10 @@ def bench_assoc(args):
                 join_traffic_src = src
         if parts:
             join_traffic, join_traffic_by_kernel = sum(parts.values()), parts
+    scan_traffic = scan_traffic_src = None
+    if world == 1:
+        v, scan_traffic_src = committed_counters("r*_pmc_traffic_assoc*.json", "assoc_scan_kernel")
+        scan_traffic = v["hbm_bytes_per_launch"] if v else None
     out = {"metric": "appearance-association pair evaluations/sec (N1 x N2 per call: the pairs the reference's double "
                      "loop visits, src/data_association.py:29-31)",
            "value": pairs / dt, "unit": "pair-evaluations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -907,6 +914,23 @@ def bench_assoc(args):
                                            if scan_valu else 1.5,
                                            "note": "exact equality forbids the distance-GEMM form; one 32-bit screening "
                                                    "test per pair on the vector ALU (about 1.5 instructions per pair)"}}}
+    if args.method == "scan":
+        # the line for the all-pairs method: every one of the N1 x N2 pairs really is evaluated
+        ds = timing["scan"]
+        peak = SIMDS * 16 * CLOCK_HZ / 1e12
+        achieved = (scan_valu["valu_wave_instructions_per_launch"] * 64 / ds / 1e12) if scan_valu else None
+        out["value"], out["ms_per_step"] = pairs / ds, ds * 1e3
+        out["steps"] = max(2, min(args.steps, 4))
+        out["config"]["method"] = "all-pairs scan (picp_set_association_mode 1): the reference's double loop, one 32-bit screening test per pair"
+        out["config"]["hash_join_ms"] = dt * 1e3
+        out["roofline"] = {"bound": "int_valu", "kernel": "assoc_scan_kernel<8> (keys as scalar operands, xor / min3 screening)",
+                           "achieved": achieved, "peak": peak, "unit": "1e12 vector lane-operations/s",
+                           "frac": (achieved / peak) if achieved else None,
+                           "peak_derivation": "1 024 SIMDs x 16 lanes per clock x 2.4 GHz (a 64-lane vector instruction "
+                                              "occupies its SIMD for 4 cycles)",
+                           "valu": scan_valu, "traffic": scan_traffic, "traffic_source": scan_traffic_src,
+                           "instructions_per_pair": out["roofline"]["all_pairs_scan"]["instructions_per_pair"],
+                           "note": "exact equality forbids the distance-GEMM form; about 1.5 vector instructions per pair"}
     if settle:
         out["settle"] = settle
     if not args.no_cpu_baseline and world == 1:

@@ -27,10 +27,16 @@ __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
 
 __device__ __forceinline__ uint32_t low_word(double d) { return (uint32_t)__double_as_longlong(d); }
 
+// n_init > 0: also clears the per-query results the split scan accumulates into (count 0, first "none").
 __global__ __launch_bounds__(ANT) void assoc_keys_kernel(const double* __restrict__ app, int64_t N, int D,
-                                                         uint32_t* __restrict__ key) {
+                                                         uint32_t* __restrict__ key, int64_t* __restrict__ count,
+                                                         int64_t* __restrict__ first, int64_t n_init) {
     const int64_t i = (int64_t)blockIdx.x * ANT + threadIdx.x;
     if (i < N) key[i] = low_word(app[i * D]);
+    if (i < n_init) {
+        count[i] = 0;
+        first[i] = INT64_MAX;
+    }
 }
 
 // Full comparison of two descriptor rows (src/data_association.py:31): list equality = every
@@ -49,11 +55,17 @@ __device__ __forceinline__ bool rows_equal(const double* __restrict__ a, const d
 // OR, nothing else -- no LDS staging, no barriers.  A lane screens R query rows per key.  Only when
 // some lane of the wave hits within a step does the wave look at that step's keys one by one.
 // key2 must be readable up to index round_up(N2, 8) + 7 (the workspace is over-allocated).
-template <int R>
+// SPLIT: the rows of set 2 are cut into gridDim.y segments of seg_len rows (a multiple of 8) and workgroup
+// (x, y) screens its query rows against segment y only -- for inputs with too few query rows to fill the
+// chip with one workgroup per 256 R of them (a rank's share of a sharded association).  The segments'
+// results meet in count / first (cleared beforehand) through integer atomics, issued only by the lanes
+// that found a match: the number of matches and the smallest matching row do not depend on the order.
+template <int R, bool SPLIT = false>
 __global__ __launch_bounds__(ANT) void assoc_scan_kernel(const double* __restrict__ app1, int64_t N1,
                                                          const double* __restrict__ app2, int64_t N2, int D,
                                                          const uint32_t* __restrict__ key2,
-                                                         int64_t* __restrict__ count, int64_t* __restrict__ first) {
+                                                         int64_t* __restrict__ count, int64_t* __restrict__ first,
+                                                         int64_t seg_len) {
     uint32_t qk[R];
     int64_t qi[R];
     int64_t cnt[R];
@@ -66,8 +78,10 @@ __global__ __launch_bounds__(ANT) void assoc_scan_kernel(const double* __restric
         fst[r] = -1;
     }
     const uint4* __restrict__ keys4 = reinterpret_cast<const uint4*>(key2);
-    uint4 na = keys4[0], nb = keys4[1];
-    for (int64_t k = 0; k < N2; k += 8) {
+    const int64_t k_begin = SPLIT ? (int64_t)blockIdx.y * seg_len : 0;
+    const int64_t k_end = SPLIT ? ((k_begin + seg_len < N2) ? k_begin + seg_len : N2) : N2;
+    uint4 na = keys4[k_begin >> 2], nb = keys4[(k_begin >> 2) + 1];
+    for (int64_t k = k_begin; k < k_end; k += 8) {
         const uint4 a = na, b = nb;
         // Scalar loads return out of order, so a wave can only wait for all of them: make the wait
         // for this step's keys happen here, before the next step's keys are requested, so that
@@ -111,8 +125,15 @@ __global__ __launch_bounds__(ANT) void assoc_scan_kernel(const double* __restric
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (qi[r] < N1) {
-            count[qi[r]] = cnt[r];
-            first[qi[r]] = fst[r];
+            if (SPLIT) {
+                if (cnt[r] > 0) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(count + qi[r]), (unsigned long long)cnt[r]);
+                    atomicMin(reinterpret_cast<unsigned long long*>(first + qi[r]), (unsigned long long)fst[r]);
+                }
+            } else {
+                count[qi[r]] = cnt[r];
+                first[qi[r]] = fst[r];
+            }
         }
     }
 }
@@ -783,17 +804,37 @@ static int scan_pass(picp_ctx* ctx, const double* app1, int64_t N1, const double
                      int64_t* idx1, int64_t* idx2, int64_t capacity, int64_t* count) {
     hipStream_t s = ctx->stream;
     const unsigned grid1 = (unsigned)((N1 + ANT - 1) / ANT);
-    hipLaunchKernelGGL(assoc_keys_kernel, dim3((unsigned)((N2 + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, D,
-                       ctx->assoc_key);
-    // Few query rows: one per lane keeps more workgroups busy; many: eight per lane amortise
-    // the key fetches and the loop overhead.
-    int rows_per_lane = (N1 >= (int64_t)ANT * 8 * ctx->num_cus) ? 8 : 1;
+    // Many query rows: eight per lane amortise the key fetches and the loop overhead, and a workgroup per
+    // 2 048 rows fills the chip.  Fewer (a rank's share of a sharded association, a frame's few hundred
+    // points): the rows of set 2 are cut into segments as well, so that rows x segments fills it.
+    int rows_per_lane = (N1 >= (int64_t)ANT * 8 * 8) ? 8 : 1;
     if (const char* e = getenv("PICP_ASSOC_ROWS_PER_LANE")) rows_per_lane = atoi(e); // tuning override
     const int R = rows_per_lane == 8 ? 8 : (rows_per_lane == 4 ? 4 : 1);
     const unsigned nbs = (unsigned)((N1 + (int64_t)ANT * R - 1) / ((int64_t)ANT * R));
-    auto kern = R == 8 ? assoc_scan_kernel<8> : (R == 4 ? assoc_scan_kernel<4> : assoc_scan_kernel<1>);
-    hipLaunchKernelGGL(kern, dim3(nbs), dim3(ANT), 0, s, app1, N1, app2, N2, D, (const uint32_t*)ctx->assoc_key,
-                       ctx->assoc_count, ctx->assoc_first);
+    constexpr int64_t MIN_SEGMENT = 8192; // rows of set 2 per segment, at least
+    int64_t segments = 1;
+    if (nbs < 2u * (unsigned)ctx->num_cus) {
+        segments = (4 * (int64_t)ctx->num_cus + nbs - 1) / nbs;
+        const int64_t most = (N2 + MIN_SEGMENT - 1) / MIN_SEGMENT;
+        if (segments > most) segments = most;
+        if (segments < 1) segments = 1;
+    }
+    if (const char* e = getenv("PICP_ASSOC_SEGMENTS")) segments = atoll(e) > 0 ? atoll(e) : 1; // tuning override
+    const int64_t seg_len = ((N2 + segments - 1) / segments + 7) / 8 * 8;
+    segments = seg_len > 0 ? (N2 + seg_len - 1) / seg_len : 1;
+    const bool split = segments > 1;
+    const int64_t n_keys_grid = (split && N1 > N2) ? N1 : N2;
+    hipLaunchKernelGGL(assoc_keys_kernel, dim3((unsigned)((n_keys_grid + ANT - 1) / ANT)), dim3(ANT), 0, s, app2, N2, D,
+                       ctx->assoc_key, ctx->assoc_count, ctx->assoc_first, split ? N1 : (int64_t)0);
+    if (split) {
+        auto kern = R == 8 ? assoc_scan_kernel<8, true> : (R == 4 ? assoc_scan_kernel<4, true> : assoc_scan_kernel<1, true>);
+        hipLaunchKernelGGL(kern, dim3(nbs, (unsigned)segments), dim3(ANT), 0, s, app1, N1, app2, N2, D,
+                           (const uint32_t*)ctx->assoc_key, ctx->assoc_count, ctx->assoc_first, seg_len);
+    } else {
+        auto kern = R == 8 ? assoc_scan_kernel<8> : (R == 4 ? assoc_scan_kernel<4> : assoc_scan_kernel<1>);
+        hipLaunchKernelGGL(kern, dim3(nbs), dim3(ANT), 0, s, app1, N1, app2, N2, D, (const uint32_t*)ctx->assoc_key,
+                           ctx->assoc_count, ctx->assoc_first, (int64_t)0);
+    }
     PICP_HIP_CHECK(hipGetLastError());
     const int64_t nb = (N1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(ANT), 0, s, (const int64_t*)ctx->assoc_count,

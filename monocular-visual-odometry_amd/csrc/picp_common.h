@@ -49,6 +49,7 @@ struct picp_ctx {
     int abort_streak;              // consecutive single-launch loops that gave up
     int single_launch_holdoff;     // picp_run calls that still go straight to the stage launches after a streak
     int64_t persistent_limit;      // largest M the streaming single-launch loop is used for (0: never)
+    int persistent_hold;           // the streaming single-launch loop keeps part of its input in LDS (PICP_PERSISTENT_HOLD=0: never)
     hipEvent_t loop_done;          // recorded behind a single-launch loop; the host waits for it, not for the stream
     hipEvent_t slot_done[PICP_ASYNC_SLOTS]; // the same for loops enqueued with picp_run_enqueue, one per slot
     int grid_limit;                // cap on the workgroups of the single-launch loops (0: one per CU)

@@ -81,6 +81,8 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     ctx->peer_spin_limit = 1u << 20; // about a second: ranks reach their launches at different times
     if (const char* ex = getenv("PICP_PEER_SPIN_LIMIT")) { int k = atoi(ex); if (k >= 0) ctx->peer_spin_limit = (unsigned)k; }
     if (const char* ep = getenv("PICP_PERSISTENT_LIMIT")) ctx->persistent_limit = atoll(ep);
+    ctx->persistent_hold = 1;
+    if (const char* eh = getenv("PICP_PERSISTENT_HOLD")) ctx->persistent_hold = atoi(eh) != 0;
     if (const char* er = getenv("PICP_RESIDENT")) { if (atoi(er) == 0) ctx->resident_limit = 0; }
     if (const char* es = getenv("PICP_RESIDENT_SPIN_LIMIT")) { int k = atoi(es); if (k >= 0) ctx->resident_spin_limit = (unsigned)k; }
     if (e != hipSuccess) {

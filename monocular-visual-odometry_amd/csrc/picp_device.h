@@ -1268,6 +1268,12 @@ struct CorrStream {
     }
     template <typename F>
     __device__ __forceinline__ void run(F&& visit) {
+        run(visit, [] {});
+    }
+    // between(): called after every step's two correspondences, while the next step's loads are in flight --
+    // for work that needs no memory (correspondences a kernel holds on chip).
+    template <typename F, typename G>
+    __device__ __forceinline__ void run(F&& visit, G&& between) {
         auto point = [&](double mu, double mv, double px, double py, double pz) {
             homogeneous_nan(px, py, pz);
             visit(mu, mv, px, py, pz);
@@ -1295,12 +1301,14 @@ struct CorrStream {
                     B = load2(u2, v2, x2, y2, z2, hasB ? j : i);
                     point(A.u.x, A.v.x, A.x.x, A.y.x, A.z.x);
                     point(A.u.y, A.v.y, A.x.y, A.y.y, A.z.y);
+                    between();
                     if (!hasB) break;
                     const int64_t k = j + hop;
                     const bool hasA = more(k);
                     A = load2(u2, v2, x2, y2, z2, hasA ? k : j);
                     point(B.u.x, B.v.x, B.x.x, B.y.x, B.z.x);
                     point(B.u.y, B.v.y, B.x.y, B.y.y, B.z.y);
+                    between();
                     if (!hasA) break;
                     i = k;
                 }
