@@ -687,13 +687,21 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
 // takes tens of microseconds.  The first loads of the next scan are issued before the exchange
 // that precedes it, so their latency is hidden behind it.
 //
-// HOLD > 0: the first HOLD * gridDim.x * NTR correspondences do not take part in the streaming: they are read
-// once, at the start of the launch, into LDS (all five values, thread-private columns [HOLD][5][NTR], 20 KB per
-// unit of HOLD), and every scan visits them from there, one of them after each streaming step while that step's
-// successor is in flight, so their arithmetic hides behind the memory traffic of the rest.  What is held on chip
-// is traffic the scans do not cause: an eighth to a ninth of a 2^23-correspondence slice with HOLD = 7.
-constexpr int PERSISTENT_HOLD = 7; // 140 KB of the CU's 160 KB, beside 10 KB of static LDS
-template <bool PINHOLE, bool REVERSE, bool SHARDED = false, int HOLD = 0>
+// HOLD + HOLDR > 0: the first (HOLD + HOLDR) * gridDim.x * NTR correspondences do not take part in the
+// streaming: they are read once, at the start of the launch, and stay on chip -- HOLD per thread with all five
+// values in LDS (thread-private columns [HOLD][5][NTR]), HOLDR per thread with the point in registers and the
+// measurement in LDS ([HOLDR][2][NTR] behind the former) -- and every scan visits them from there, one of them
+// after each streaming step while that step's successor is in flight, so their arithmetic hides behind the
+// memory traffic of the rest.  What is held on chip is traffic the scans do not cause: an eighth of a
+// 2^23-correspondence slice.
+#ifndef PICP_HOLD
+#define PICP_HOLD 5
+#define PICP_HOLDR 5
+#endif
+constexpr int PERSISTENT_HOLD = PICP_HOLD;   // 100 KB of LDS ...
+constexpr int PERSISTENT_HOLDR = PICP_HOLDR; // ... + 40 KB and 30 registers per lane, beside 10 KB of static LDS
+static_assert((PERSISTENT_HOLD * 5 + PERSISTENT_HOLDR * 2) * NTR * sizeof(double) <= 146 * 1024, "LDS of the held correspondences");
+template <bool PINHOLE, bool REVERSE, bool SHARDED = false, int HOLD = 0, int HOLDR = 0>
 __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                             const double* __restrict__ x, const double* __restrict__ y,
                                                             const double* __restrict__ z, int64_t M,
@@ -709,31 +717,52 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
     __shared__ double row[PICP_HIST_STRIDE];
     __shared__ int flag;
     __shared__ StepShared sh;
-    extern __shared__ double held[]; // [HOLD][5][NTR]: u, v, x, y, z of the correspondences kept on chip
+    extern __shared__ double held[]; // [HOLD][5][NTR] u, v, x, y, z, then [HOLDR][2][NTR] u, v: the correspondences kept on chip
+    constexpr int HELD = HOLD + HOLDR;
+    // (vector values, not arrays: an array that is indexed with the loop-carried `h` ends up in scratch memory)
+    typedef double HeldVec __attribute__((ext_vector_type(HOLDR > 0 ? HOLDR : 1)));
+    [[maybe_unused]] HeldVec rx, ry, rz;
     const int64_t M_all = M;
-    if (HOLD > 0) { // the streams cover what is not held (an even number is held: the rest stays 16-byte aligned)
-        const int64_t M_held = (int64_t)HOLD * gridDim.x * NTR;
+    if (HELD > 0) { // the streams cover what is not held (an even number is held: the rest stays 16-byte aligned)
+        const int64_t M_held = (int64_t)HELD * gridDim.x * NTR;
         u += M_held, v += M_held, x += M_held, y += M_held, z += M_held;
         M -= M_held;
     }
     CorrStream<2, NTR, false> fwd;
     CorrStream<2, NTR, REVERSE> rev; // stage 2's direction: see stage2_reverse()
     fwd.start(u, v, x, y, z, M);
-    if (HOLD > 0) {
+    if (HELD > 0) {
         const int64_t M_held = M_all - M;
         const double *u0 = u - M_held, *v0 = v - M_held, *x0 = x - M_held, *y0 = y - M_held, *z0 = z - M_held;
 #pragma unroll
-        for (int h = 0; h < HOLD; ++h) {
+        for (int h = 0; h < HELD; ++h) {
             const int64_t i = ((int64_t)h * gridDim.x + blockIdx.x) * NTR + threadIdx.x; // < M_held <= M_all (host)
             double px = x0[i], py = y0[i], pz = z0[i];
             homogeneous_nan(px, py, pz);
-            held[(h * 5 + 0) * NTR + threadIdx.x] = u0[i];
-            held[(h * 5 + 1) * NTR + threadIdx.x] = v0[i];
-            held[(h * 5 + 2) * NTR + threadIdx.x] = px;
-            held[(h * 5 + 3) * NTR + threadIdx.x] = py;
-            held[(h * 5 + 4) * NTR + threadIdx.x] = pz;
+            if (h < HOLD) {
+                held[(h * 5 + 0) * NTR + threadIdx.x] = u0[i];
+                held[(h * 5 + 1) * NTR + threadIdx.x] = v0[i];
+                held[(h * 5 + 2) * NTR + threadIdx.x] = px;
+                held[(h * 5 + 3) * NTR + threadIdx.x] = py;
+                held[(h * 5 + 4) * NTR + threadIdx.x] = pz;
+            } else {
+                held[(HOLD * 5 + (h - HOLD) * 2 + 0) * NTR + threadIdx.x] = u0[i];
+                held[(HOLD * 5 + (h - HOLD) * 2 + 1) * NTR + threadIdx.x] = v0[i];
+                rx[h - HOLD] = px, ry[h - HOLD] = py, rz[h - HOLD] = pz;
+            }
         }
     }
+    // Visits held correspondence h (the same h in every thread).
+    auto visit_held = [&](int h, auto&& visit) __attribute__((always_inline)) {
+        if (h < HOLD) {
+            const double* c = held + (size_t)(h * 5) * NTR + threadIdx.x;
+            visit(c[0], c[NTR], c[2 * NTR], c[3 * NTR], c[4 * NTR]);
+        } else if (HOLDR > 0) {
+            const int r = h - HOLD;
+            const double* c = held + (size_t)(HOLD * 5 + r * 2) * NTR + threadIdx.x;
+            visit(c[0], c[NTR], rx[r], ry[r], rz[r]);
+        }
+    };
     restore_other_set(gx);
     if (threadIdx.x == 0) {
         init_state(st, pose0.m, sc.kernel_threshold, sc.damping, sc.num_iterations);
@@ -752,20 +781,15 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
         const int it = (int)st[ST_IT];
 
         Stage1Sums a{0.0, 0u, 0u};
-        auto visit1 = [&](double mu, double mv, double qx, double qy, double qz) {
+        auto visit1 = [&](double mu, double mv, double qx, double qy, double qz) __attribute__((always_inline)) {
             stage1_point<PINHOLE>(T, cam, thr, mu, mv, qx, qy, qz, a);
         };
-        if (HOLD > 0) {
+        if (HELD > 0) {
             int h = 0; // the same in every thread: the held correspondences are visited one per streaming step
-            auto one_held = [&] {
-                const double* c = held + (size_t)(h * 5) * NTR + threadIdx.x;
-                visit1(c[0], c[NTR], c[2 * NTR], c[3 * NTR], c[4 * NTR]);
-                ++h;
-            };
-            fwd.run(visit1, [&] {
-                if (h < HOLD) one_held();
+            fwd.run(visit1, [&]() __attribute__((always_inline)) {
+                if (h < HELD) visit_held(h++, visit1);
             });
-            while (h < HOLD) one_held();
+            while (h < HELD) visit_held(h++, visit1);
         } else {
             fwd.run(visit1);
         }
@@ -787,20 +811,15 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
             const double mean = uniform(s1[S1_SUM_CHI] / n1); // np.mean, src/ProjectiveICP.py:301
             Stage2Sums s;
             s.clear();
-            auto visit2 = [&](double mu, double mv, double qx, double qy, double qz) {
+            auto visit2 = [&](double mu, double mv, double qx, double qy, double qz) __attribute__((always_inline)) {
                 stage2_point<PINHOLE>(T, cam, thr, mean, all, mu, mv, qx, qy, qz, s);
             };
-            if (HOLD > 0) {
+            if (HELD > 0) {
                 int h = 0;
-                auto one_held = [&] {
-                    const double* c = held + (size_t)(h * 5) * NTR + threadIdx.x;
-                    visit2(c[0], c[NTR], c[2 * NTR], c[3 * NTR], c[4 * NTR]);
-                    ++h;
-                };
-                rev.run(visit2, [&] {
-                    if (h < HOLD) one_held();
+                rev.run(visit2, [&]() __attribute__((always_inline)) {
+                    if (h < HELD) visit_held(h++, visit2);
                 });
-                while (h < HOLD) one_held();
+                while (h < HELD) visit_held(h++, visit2);
             } else {
                 rev.run(visit2);
             }
@@ -1128,20 +1147,20 @@ int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const do
     const bool pin = is_pinhole(cam->K);
     const bool rev = stage2_reverse(ctx, M);
     // Part of the input on chip for the whole launch when at least one full streaming step is left beside it.
-    const bool hold = ctx->persistent_hold && M >= (int64_t)(PERSISTENT_HOLD + 2) * grid * NTR;
+    const bool hold = ctx->persistent_hold && M >= (int64_t)(PERSISTENT_HOLD + PERSISTENT_HOLDR + 2) * grid * NTR;
     using Kern = void (*)(const double*, const double*, const double*, const double*, const double*, int64_t, double*,
                           StartPose, CameraK, picp_schedule, GridExchange, double*, int, double*, PeerExchange);
     static const Kern table[2][2][2][2] = {
-        {{{icp_persistent_kernel<false, false, false, 0>, icp_persistent_kernel<true, false, false, 0>},
-          {icp_persistent_kernel<false, true, false, 0>, icp_persistent_kernel<true, true, false, 0>}},
-         {{icp_persistent_kernel<false, false, true, 0>, icp_persistent_kernel<true, false, true, 0>},
-          {icp_persistent_kernel<false, true, true, 0>, icp_persistent_kernel<true, true, true, 0>}}},
-        {{{icp_persistent_kernel<false, false, false, PERSISTENT_HOLD>, icp_persistent_kernel<true, false, false, PERSISTENT_HOLD>},
-          {icp_persistent_kernel<false, true, false, PERSISTENT_HOLD>, icp_persistent_kernel<true, true, false, PERSISTENT_HOLD>}},
-         {{icp_persistent_kernel<false, false, true, PERSISTENT_HOLD>, icp_persistent_kernel<true, false, true, PERSISTENT_HOLD>},
-          {icp_persistent_kernel<false, true, true, PERSISTENT_HOLD>, icp_persistent_kernel<true, true, true, PERSISTENT_HOLD>}}}};
+        {{{icp_persistent_kernel<false, false, false, 0, 0>, icp_persistent_kernel<true, false, false, 0, 0>},
+          {icp_persistent_kernel<false, true, false, 0, 0>, icp_persistent_kernel<true, true, false, 0, 0>}},
+         {{icp_persistent_kernel<false, false, true, 0, 0>, icp_persistent_kernel<true, false, true, 0, 0>},
+          {icp_persistent_kernel<false, true, true, 0, 0>, icp_persistent_kernel<true, true, true, 0, 0>}}},
+        {{{icp_persistent_kernel<false, false, false, PERSISTENT_HOLD, PERSISTENT_HOLDR>, icp_persistent_kernel<true, false, false, PERSISTENT_HOLD, PERSISTENT_HOLDR>},
+          {icp_persistent_kernel<false, true, false, PERSISTENT_HOLD, PERSISTENT_HOLDR>, icp_persistent_kernel<true, true, false, PERSISTENT_HOLD, PERSISTENT_HOLDR>}},
+         {{icp_persistent_kernel<false, false, true, PERSISTENT_HOLD, PERSISTENT_HOLDR>, icp_persistent_kernel<true, false, true, PERSISTENT_HOLD, PERSISTENT_HOLDR>},
+          {icp_persistent_kernel<false, true, true, PERSISTENT_HOLD, PERSISTENT_HOLDR>, icp_persistent_kernel<true, true, true, PERSISTENT_HOLD, PERSISTENT_HOLDR>}}}};
     const Kern kern = table[hold ? 1 : 0][sharded ? 1 : 0][rev ? 1 : 0][pin ? 1 : 0];
-    const unsigned held_bytes = hold ? PERSISTENT_HOLD * 5 * NTR * sizeof(double) : 0;
+    const unsigned held_bytes = hold ? (PERSISTENT_HOLD * 5 + PERSISTENT_HOLDR * 2) * NTR * sizeof(double) : 0;
     if (hold) { // above the default dynamic-LDS allowance: raise it once per kernel and device
         static bool raised[8][MAX_DEVICES] = {};
         const int which = (sharded ? 4 : 0) + (rev ? 2 : 0) + (pin ? 1 : 0);
