@@ -124,14 +124,18 @@ int picp_run(picp_ctx* ctx, const double* u, const double* v, const double* x, c
  *  - up to picp_resident_capacity(ctx) correspondences the whole loop is ONE launch that reads the
  *    five arrays once and keeps them in registers and LDS, exchanging the two per-iteration sums of
  *    :301 and :313-317 between workgroups inside the kernel;
- *  - larger inputs (16-byte aligned arrays) run the whole loop in one launch as well, with the arrays
- *    streamed from memory twice per iteration and the same in-kernel exchange;
+ *  - larger inputs (16-byte aligned arrays) run the whole loop in one launch as well, with the same
+ *    in-kernel exchange: the first 5 120 correspondences per compute unit stay in LDS and registers
+ *    for the whole launch, the rest of the arrays is streamed from memory twice per iteration;
  *  - otherwise, and as the fallback of the other two, every iteration is three launches (two scans
  *    and the solve step).
  * picp_set_resident_limit lowers the switch point between the first two (0 = always the per-iteration
  * launches); the capacity is a property of the device (CUs x threads x registers). */
 int picp_set_resident_limit(picp_ctx* ctx, int64_t max_correspondences);
 int64_t picp_resident_capacity(picp_ctx* ctx);
+/* How many of M correspondences the second path keeps on chip for the whole launch (0 when M leaves less
+ * than one full streaming step beside them): what its scans do not read from memory again. */
+int64_t picp_streaming_held(picp_ctx* ctx, int64_t M);
 /* The single launch waits for all of its workgroups at every exchange, with a bound on each wait.  If
  * the device is shared and part of the grid is not scheduled, the launch gives up and picp_run
  * repeats the loop with the streaming kernels; this returns how often that has happened on ctx. */
@@ -263,7 +267,8 @@ int picp_sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const d
  * picp_run_sharded runs the loop on this rank's slice (M may be 0) and synchronises; every rank must
  * call it with the same pose, camera and schedule.  Results as picp_run, identical on all ranks.
  * A slice that fits the register files of the GPU (picp_resident_capacity) is held on chip for the
- * whole loop, a larger or empty one is streamed from memory twice per iteration; the two forms run
+ * whole loop, a larger or empty one is streamed from memory twice per iteration (all but a part of it
+ * that the kernel keeps on chip, as picp_run does at such sizes); the two forms run
  * the same exchanges, so the choice is each rank's own (picp_set_resident_limit(ctx, 0): always stream).
  * Every wait inside the kernel is bounded: if a peer's record does not arrive (a rank died or was
  * never launched) the launch gives up, the call returns PICP_ERR_RETRY and the exchange is unusable

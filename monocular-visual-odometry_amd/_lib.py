@@ -88,6 +88,7 @@ _SIGNATURES = {
     "picp_run_collect": (C.c_int, [_P, C.c_int32, _P, C.POINTER(ResultStruct)]),
     "picp_set_resident_limit": (C.c_int, [_P, C.c_int64]),
     "picp_resident_capacity": (C.c_int64, [_P]),
+    "picp_streaming_held": (C.c_int64, [_P, C.c_int64]),
     "picp_resident_aborts": (C.c_int, [_P]),
     "picp_immoderate_exits": (C.c_int, [_P]),
     "picp_profile_run": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(CameraStruct),
@@ -286,6 +287,10 @@ class Context:
 
     def resident_capacity(self):
         return int(self.lib.picp_resident_capacity(self.handle))
+
+    def streaming_held(self, M):
+        """Correspondences of an M-correspondence input that the streaming single launch keeps on chip."""
+        return int(self.lib.picp_streaming_held(self.handle, int(M)))
 
     def resident_aborts(self):
         """Single-launch loops that gave up at a grid-wide wait and were repeated with the streaming kernels."""

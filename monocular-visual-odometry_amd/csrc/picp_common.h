@@ -111,6 +111,7 @@ int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const do
                        hipEvent_t e1, bool sharded = false);
 void peer_fill(picp_ctx* ctx, double* slots);
 int peer_slot_doubles();
+int64_t persistent_held(const picp_ctx* ctx, int64_t M);
 
 // Whether the second scan of an iteration walks the arrays against the first one's direction: it
 // then starts with what stage 1 read last and ends with what the next stage 1 reads first, which

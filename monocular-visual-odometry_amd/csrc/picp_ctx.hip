@@ -152,6 +152,7 @@ int picp_set_stage2_order(picp_ctx* ctx, int32_t order) {
 }
 
 int64_t picp_resident_capacity(picp_ctx* ctx) { return ctx ? resident_capacity(ctx) : 0; }
+int64_t picp_streaming_held(picp_ctx* ctx, int64_t M) { return (ctx && M > 0) ? persistent_held(ctx, M) : 0; }
 
 int picp_resident_aborts(picp_ctx* ctx) { return ctx ? ctx->resident_aborts : 0; }
 int picp_immoderate_exits(picp_ctx* ctx) { return ctx ? ctx->immoderate_exits : 0; }

@@ -1180,6 +1180,14 @@ int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const do
     return PICP_OK;
 }
 
+// Correspondences of an M-correspondence input (or slice) that the streaming single launch keeps on chip.
+int64_t persistent_held(const picp_ctx* ctx, int64_t M) {
+    const int64_t steps = ((M >> 1) + NTR - 1) / NTR;
+    const int64_t grid = steps < 1 ? 1 : (steps > resident_grid(ctx) ? resident_grid(ctx) : steps);
+    const bool hold = ctx->persistent_hold && M >= (int64_t)(PERSISTENT_HOLD + PERSISTENT_HOLDR + 2) * grid * NTR;
+    return hold ? (int64_t)(PERSISTENT_HOLD + PERSISTENT_HOLDR) * grid * NTR : 0;
+}
+
 int peer_slot_doubles() { return XS * XR * RW; }
 
 // Sentinels into a rank's exchange memory for the GPUs (set-up only).

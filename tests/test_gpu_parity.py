@@ -623,6 +623,42 @@ def test_beyond_the_on_chip_capacity_one_launch_streams(ctx):
     assert rel_err(np.array(list(res.T)).reshape(4, 4), T_ref) < TOL
 
 
+@pytest.mark.parametrize("order", ["forward", "reverse"])
+@pytest.mark.parametrize("general_camera", [False, True])
+def test_streaming_single_launch_with_part_of_the_input_held_on_chip(ctx, order, general_camera):
+    """The single launch that streams its arrays keeps ten correspondences per thread in LDS and registers
+    as soon as at least one full streaming step is left beside them (12 x 512 x one workgroup per compute
+    unit correspondences).  Around that size -- one below (nothing held), exactly (one streaming step),
+    one above (an odd tail), and with a ragged second step -- against the C restatement of the reference
+    loop: counts, thresholds and damping exact, H entry by entry and poses within 1e-9; both directions of
+    the second scan, the pinhole and the general camera matrix."""
+    from oracle import picp_oracle_c as oc
+    cus = ctx.resident_capacity() // (512 * 16)
+    edge = 12 * 512 * cus
+    K = [[180, 0.5, 320], [0, 175, 240], [0, 0, 1]] if general_camera else [[180, 0, 320], [0, 180, 240], [0, 0, 1]]
+    cam = L.camera_struct(K, 640, 480)
+    sched = yaml_sched(4, disable_stop=True)
+    params = po.IcpParams(num_iterations=4, disable_stop=True, K=np.array(K, dtype=np.float64))
+    uv_all, pw_all, _ = make_problem(edge + 300_001, seed=77)
+    try:
+        ctx.set_resident_limit(1)                       # every size through the streaming single launch
+        ctx.set_stage2_order(order)
+        for M in (edge - 1, edge, edge + 1, edge + 300_001):
+            uv, pw = uv_all[:M], pw_all[:M]
+            res, hist = ctx.run(ctx.soa(uv, pw), np.eye(4), cam, sched)
+            _, valid_ref, rows, best_ref = oc.projective_icp(uv, pw, np.eye(4), params)
+            assert res.num_iterations == 4 == len(rows), M
+            for col in (L.H_NUM_INLIERS, L.H_N_INSIDE, L.H_N_STAGE1, L.H_N_STAGE2, L.H_KERNEL_THR, L.H_DAMPING):
+                assert np.array_equal(hist[:, col], rows[:, col]), (M, col)
+            assert rel_err(hist[:, L.H_T:L.H_T + 16], rows[:, L.H_T:L.H_T + 16]) < TOL, M
+            for k in range(4):
+                assert entry_err(hist[k, L.H_H:L.H_H + 36], rows[k, L.H_H:L.H_H + 36]) < TOL, (M, k)
+            assert ctx.resident_aborts() == 0
+    finally:
+        ctx.set_resident_limit(None)
+        ctx.set_stage2_order("auto")
+
+
 @pytest.mark.parametrize("M", [2, 3, 1000, 262_149, 700_001, 1 << 21])
 def test_stage2_scan_order(ctx, M):
     """The streaming loop with its second scan walking the arrays forward and backward: the same pairs

@@ -24,5 +24,10 @@ for CFG in $CONFIGS; do
   timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d ${P}_sq -- python3 bench.py $ARGS > ${P}_sq.log 2>&1 || { echo "sq $CFG failed"; exit 1; }
   timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d ${P}_fetch -- python3 bench.py $ARGS > ${P}_fetch.log 2>&1 || { echo "fetch $CFG failed"; exit 1; }
   timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d ${P}_write -- python3 bench.py $ARGS > ${P}_write.log 2>&1 || { echo "write $CFG failed"; exit 1; }
+  # the small summaries kept under profiles/ (the trace and counter directories themselves are scratch)
+  python3 profiles/summarize.py stats ${P}_stats > gpurun_out/${TAG}_${CFG}_kernel_stats.csv
+  python3 profiles/summarize.py counters ${P}_sq > gpurun_out/${TAG}_pmc_sq_${CFG}.json
+  python3 profiles/summarize.py pmc ${P}_fetch ${P}_write > gpurun_out/${TAG}_pmc_traffic_${CFG}.json
+  rm -rf ${P}_stats ${P}_fetch ${P}_write ${P}_sq
   echo "$CFG done"
 done
