@@ -258,6 +258,11 @@ def init_peer_exchange(ctx, group=None):
     return ok
 
 
+def peer_world(ctx):
+    """Ranks of the ctx's usable in-kernel exchange (0: none, or shut down after a failure)."""
+    return int(ctx.lib.picp_peer_world(ctx.handle))
+
+
 def peer_memory_kind(ctx):
     """How the ctx's exchange memory was allocated ("uncached device memory", or "fine-grained device memory"
     where the former is refused; "none" without an exchange)."""
