@@ -289,6 +289,8 @@ def run_peer(ctx, corr, w_T_c0, cam, sched, want_history=True, group=None, fallb
     res = hist = None
     ok = True
     try:
+        if _injected("run_peer"):                  # rehearsal: this rank never launches, its peers run into their bound
+            raise _lib.PicpRetry("injected failure (PICP_INJECT_FAILURE=run_peer)")
         res, hist = ctx.run_sharded(corr, w_T_c0, cam, sched, want_history=want_history)
     except _lib.PicpError:
         ok = False

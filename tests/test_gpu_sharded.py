@@ -325,6 +325,73 @@ def test_two_ranks_exchange_inside_the_loop_on_slices_of_benchmark_size(monkeypa
     assert rel_err(T0, rows[best0, L.H_T:L.H_T + 16].reshape(4, 4)) < 1e-9
 
 
+def _run_peer_rank_entry(rank, world, port, out):
+    _reporting(_run_peer_rank)(rank, world, port, out)
+
+
+def _run_peer_rank(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = importlib.import_module("monocular-visual-odometry_amd")
+    os.environ["PICP_PEER_SPIN_LIMIT"] = "20000"       # the abandoned rank gives up after milliseconds, not a second
+    ctx = p._lib.Context(0)
+    ctx.set_grid_limit(192 // world)
+    cam, sched = _cam_sched(12, False)
+    uv, pw, _ = make_problem(40_001, seed=5)
+    lo, hi = p.sharded.shard_bounds(len(uv), rank, world)
+    corr = ctx.soa(uv[lo:hi], pw[lo:hi])
+    got = []
+    for inject in ("", "run_peer"):
+        assert p.sharded.init_peer_exchange(ctx)
+        os.environ["PICP_INJECT_FAILURE"] = inject
+        res, hist, used_peer = p.sharded.run_peer(ctx, corr, np.eye(4), cam, sched)
+        os.environ["PICP_INJECT_FAILURE"] = ""
+        got.append((used_peer, p.sharded.peer_world(ctx), int(res.num_iterations), int(res.best_index),
+                    np.array(list(res.T)).reshape(4, 4), hist[:, p._lib.H_NUM_INLIERS].astype(int).tolist()))
+        if p.sharded.peer_world(ctx):
+            p.sharded.shutdown_peer_exchange(ctx)
+    out.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_peer_agrees_on_the_outcome_and_falls_back_together():
+    """sharded.run_peer: with a healthy exchange both ranks use it; when one rank never launches (injected), the
+    other runs into its bounded wait, both learn that the loop failed somewhere, both shut the exchange down and
+    run the same loop through the stage launches -- and every rank returns the oracle's result either way."""
+    world = 2
+    uv, pw, _ = make_problem(40_001, seed=5)
+    T_ref, valid_ref, h_ref = po.projective_icp(uv, pw, np.eye(4), po.IcpParams(num_iterations=12))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpctx = mp.get_context("spawn")
+    out = mpctx.Queue()
+    procs = [mpctx.Process(target=_run_peer_rank_entry, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    for _ in procs:
+        item = out.get(timeout=150)
+        if item[1] == "error":
+            for p in procs:
+                p.kill()
+            pytest.fail(f"rank {item[0]} failed: {item[2]}")
+        got.append(item)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, runs in got:
+        (used0, world0, *_), (used1, world1, *_) = runs
+        assert used0 is True and world0 == world            # healthy: the in-kernel exchange ran
+        assert used1 is False and world1 == 0               # injected: everyone fell back, the exchange is gone
+        for used, _, n_it, best, T, n_inl in runs:
+            assert n_it == len(h_ref["error"]) and n_inl == h_ref["num_inliers"], (rank, used)
+            assert rel_err(T, T_ref) < 1e-9, (rank, used)
+    assert np.array_equal(got[0][1][0][4], got[1][1][0][4]) and np.array_equal(got[0][1][1][4], got[1][1][1][4])
+
+
 @pytest.mark.parametrize("check_every", [1, 3, 64])
 def test_whole_rounds_on_degenerate_problems(check_every):
     """picp_sharded_rounds (each scan folds its own records, the solve step runs in the next stage 1) on
