@@ -19,6 +19,7 @@ struct picp_ctx {
     double* part2;    // [max_blocks2][PICP_S2_DOUBLES]
     int rows1, rows2; // rows written by the last stage-1 / stage-2 launch
     int stage2_reverse; // stage 2 walks the arrays against stage 1's direction: 1 always, 0 never, -1 by size
+    int scan_nontemporal; // the scans' loads carry the non-temporal hint: 1 always, 0 never, -1 by size
     double* scratch;  // small device scratch: state block + s1 + s2 + misc (see offsets below)
     unsigned* arrive; // [2] arrival counters of the sharded rounds' scans (zero between launches)
     // association workspace, grown on demand
@@ -122,6 +123,13 @@ inline bool stage2_reverse(const picp_ctx* ctx, int64_t M) {
     const int64_t bytes = M * 5 * (int64_t)sizeof(double);
     return ctx->stage2_reverse < 0 ? (bytes > (int64_t(64) << 20) && bytes <= (int64_t(512) << 20))
                                    : ctx->stage2_reverse != 0;
+}
+// Whether the scans of an M-correspondence input use non-temporal loads: arrays beyond what the memory-side
+// cache can help with (the same 512 MB up to which the second scan runs backwards; swept in 48 MB steps around
+// it: 503 MB a tie, 545 MB 169 -> 155 us per iteration, 671 MB 221 -> 199 us).  PICP_NONTEMPORAL=0/1 overrides.
+inline bool scan_nontemporal(const picp_ctx* ctx, int64_t M) {
+    const int64_t bytes = M * 5 * (int64_t)sizeof(double);
+    return ctx->scan_nontemporal < 0 ? (bytes > (int64_t(512) << 20) && !stage2_reverse(ctx, M)) : ctx->scan_nontemporal != 0;
 }
 
 struct DeviceGuard {

@@ -63,6 +63,8 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     if (const char* e2 = getenv("PICP_STAGE2_WG_PER_CU")) { int k = atoi(e2); if (k >= 1 && k <= 4) ctx->max_blocks2 = k * ctx->num_cus; }
     ctx->stage2_reverse = -1; // by size (picp_stage2)
     if (const char* e3 = getenv("PICP_STAGE2_REVERSE")) ctx->stage2_reverse = atoi(e3) != 0;
+    ctx->scan_nontemporal = -1; // by size (scan_nontemporal())
+    if (const char* e4 = getenv("PICP_NONTEMPORAL")) ctx->scan_nontemporal = atoi(e4) != 0;
     hipError_t e = hipMalloc(&ctx->part1, sizeof(double) * PICP_S1_DOUBLES * ctx->max_blocks1);
     if (e == hipSuccess) e = hipMalloc(&ctx->part2, sizeof(double) * PICP_S2_DOUBLES * ctx->max_blocks2);
     if (e == hipSuccess) e = hipMalloc(&ctx->scratch, sizeof(double) * SCR_DOUBLES);

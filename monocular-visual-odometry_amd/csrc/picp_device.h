@@ -1225,20 +1225,42 @@ __device__ __forceinline__ void pack_sets(const Stage2Sums& s, double (&vals)[S2
 
 // ---- streaming the correspondence arrays --------------------------------------------------------
 // Five 16-byte loads = two correspondences per lane.
+// NONTEMPORAL: the loads carry the non-temporal hint (global_load_dwordx4 ... nt).  For arrays far beyond the
+// 256 MB memory-side cache nothing that is read will be there when the next scan comes round, and loads that
+// do not try to keep it stream faster: 2^24 correspondences (671 MB) 221 -> 199 us per iteration, 2^26 860 ->
+// 800 us (6.7 TB/s).  Below about 512 MB the cache does serve part of every scan and the hint costs that:
+// 2^23 (335 MB) 86 -> 101 us.
 struct Corr2 {
     double2 u, v, x, y, z;
 };
+template <bool NONTEMPORAL = false>
 __device__ __forceinline__ Corr2 load2(const double2* __restrict__ u, const double2* __restrict__ v,
                                        const double2* __restrict__ x, const double2* __restrict__ y,
                                        const double2* __restrict__ z, int64_t i) {
     Corr2 c;
-    c.u = u[i];
-    c.v = v[i];
-    c.x = x[i];
-    c.y = y[i];
-    c.z = z[i];
+    if constexpr (NONTEMPORAL) {
+        typedef double nt2 __attribute__((ext_vector_type(2)));
+        auto nt = [](const double2* p) {
+            const nt2 t = __builtin_nontemporal_load(reinterpret_cast<const nt2*>(p));
+            return double2{t.x, t.y};
+        };
+        c.u = nt(u + i);
+        c.v = nt(v + i);
+        c.x = nt(x + i);
+        c.y = nt(y + i);
+        c.z = nt(z + i);
+    } else {
+        c.u = u[i];
+        c.v = v[i];
+        c.x = x[i];
+        c.y = y[i];
+        c.z = z[i];
+    }
     return c;
 }
+
+// How a scan walks the arrays (CorrStream's ORDER).
+enum : int { SCAN_FORWARD = 0, SCAN_REVERSE = 1, SCAN_FORWARD_NONTEMPORAL = 2 };
 
 // Streams a workgroup grid's share of the correspondences through `point(mu, mv, x, y, z)`.
 // VEC == 2: 16-byte loads; the loads of the next grid-stride step are issued before the current
@@ -1248,8 +1270,11 @@ __device__ __forceinline__ Corr2 load2(const double2* __restrict__ u, const doub
 // REVERSE: every thread visits its grid-stride steps from the last to the first.  A scan that runs
 // against the direction of the scan before it starts with the data that scan read last, which the
 // memory-side cache still holds when the arrays are larger than the cache.
-template <int VEC, int THREADS, bool REVERSE = false>
+// ORDER = SCAN_FORWARD_NONTEMPORAL: forward, with non-temporal loads (load2).
+template <int VEC, int THREADS, int ORDER = SCAN_FORWARD>
 struct CorrStream {
+    static constexpr bool REVERSE = (ORDER == SCAN_REVERSE);
+    static constexpr bool NONTEMPORAL = (ORDER == SCAN_FORWARD_NONTEMPORAL);
     const double *u, *v, *x, *y, *z;
     int64_t M, stride, tid, head;
     Corr2 A;
@@ -1262,7 +1287,7 @@ struct CorrStream {
         // the thread's first step: index tid going up, its last grid-stride index going down
         head = (REVERSE && tid < n2) ? tid + (n2 - 1 - tid) / stride * stride : tid;
         if (VEC == 2 && tid < n2)
-            A = load2(reinterpret_cast<const double2*>(u), reinterpret_cast<const double2*>(v),
+            A = load2<NONTEMPORAL>(reinterpret_cast<const double2*>(u), reinterpret_cast<const double2*>(v),
                       reinterpret_cast<const double2*>(x), reinterpret_cast<const double2*>(y),
                       reinterpret_cast<const double2*>(z), head);
     }
@@ -1298,14 +1323,14 @@ struct CorrStream {
                 for (;;) {
                     const int64_t j = i + hop;
                     const bool hasB = more(j);
-                    B = load2(u2, v2, x2, y2, z2, hasB ? j : i);
+                    B = load2<NONTEMPORAL>(u2, v2, x2, y2, z2, hasB ? j : i);
                     point(A.u.x, A.v.x, A.x.x, A.y.x, A.z.x);
                     point(A.u.y, A.v.y, A.x.y, A.y.y, A.z.y);
                     between();
                     if (!hasB) break;
                     const int64_t k = j + hop;
                     const bool hasA = more(k);
-                    A = load2(u2, v2, x2, y2, z2, hasA ? k : j);
+                    A = load2<NONTEMPORAL>(u2, v2, x2, y2, z2, hasA ? k : j);
                     point(B.u.x, B.v.x, B.x.x, B.y.x, B.z.x);
                     point(B.u.y, B.v.y, B.x.y, B.y.y, B.z.y);
                     between();

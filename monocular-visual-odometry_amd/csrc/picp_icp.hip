@@ -30,14 +30,14 @@ __global__ void state_init_kernel(double* st, Pose16 pose, double thr, double la
 }
 
 // ---- stage 1 --------------------------------------------------------------------------------
-template <int VEC, bool PINHOLE, int THREADS = NT>
+template <int VEC, bool PINHOLE, int THREADS = NT, int ORDER = SCAN_FORWARD>
 __global__ __launch_bounds__(THREADS) void stage1_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                     const double* __restrict__ x, const double* __restrict__ y,
                                                     const double* __restrict__ z, int64_t M,
                                                     const double* __restrict__ state, CameraK cam,
                                                     double* __restrict__ part) {
     __shared__ double lds[(THREADS / 64) * 64];
-    CorrStream<VEC, THREADS> stream;
+    CorrStream<VEC, THREADS, ORDER> stream;
     stream.start(u, v, x, y, z, M); // first loads in flight before the state block is read
     if (state[ST_STOP] != 0.0) return;
     double T[12];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(THREADS) void stage1_kernel(const double* __restric
 }
 
 // ---- stage 2 --------------------------------------------------------------------------------
-template <int VEC, bool PINHOLE, bool REVERSE = false>
+template <int VEC, bool PINHOLE, int REVERSE = SCAN_FORWARD> // REVERSE: the scan's ORDER (CorrStream)
 __global__ __launch_bounds__(NT2) void stage2_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                     const double* __restrict__ x, const double* __restrict__ y,
                                                     const double* __restrict__ z, int64_t M,
@@ -193,7 +193,7 @@ __device__ __forceinline__ void fold_by_last_arrival(double tot, double* __restr
     if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // for the next launch
 }
 
-template <int VEC, bool PINHOLE, int THREADS>
+template <int VEC, bool PINHOLE, int THREADS, int ORDER = SCAN_FORWARD>
 __global__ __launch_bounds__(THREADS) void stage1_round_kernel(
     const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ x, const double* __restrict__ y,
     const double* __restrict__ z, int64_t M, const double* __restrict__ state_in, double* __restrict__ state_out,
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(THREADS) void stage1_round_kernel(
     __shared__ double row[PICP_HIST_STRIDE];
     __shared__ StepShared sh;
     __shared__ int last;
-    CorrStream<VEC, THREADS> stream;
+    CorrStream<VEC, THREADS, ORDER> stream;
     stream.start(u, v, x, y, z, M); // first loads in flight before anything else
     if (threadIdx.x < PICP_STATE_DOUBLES) st[threadIdx.x] = state_in[threadIdx.x];
     if (do_solve) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(THREADS) void stage1_round_kernel(
     fold_by_last_arrival<3, PICP_S1_DOUBLES, THREADS>(tot, part, counter, s1_out, lds, &last);
 }
 
-template <int VEC, bool PINHOLE, bool REVERSE>
+template <int VEC, bool PINHOLE, int REVERSE> // REVERSE: the scan's ORDER (CorrStream)
 __global__ __launch_bounds__(NT2) void stage2_round_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                           const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, int64_t M,
@@ -462,6 +462,9 @@ static int launch_stage1(picp_ctx* ctx, const double* u, const double* v, const 
         PICP_HIP_CHECK(hipGetLastError());
         return PICP_OK;
     }
+    if (vec && scan_nontemporal(ctx, M)) // arrays far beyond the memory-side cache: non-temporal loads
+        kern = is_pinhole(cam->K) ? stage1_kernel<2, true, NT, SCAN_FORWARD_NONTEMPORAL>
+                                  : stage1_kernel<2, false, NT, SCAN_FORWARD_NONTEMPORAL>;
     *rows = grid;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, ctx->stream, u, v, x, y, z, M, state, c, part);
     PICP_HIP_CHECK(hipGetLastError());
@@ -480,7 +483,9 @@ static int launch_stage2(picp_ctx* ctx, const double* u, const double* v, const 
     auto kern = vec ? (is_pinhole(cam->K) ? stage2_kernel<2, true> : stage2_kernel<2, false>)
                     : (is_pinhole(cam->K) ? stage2_kernel<1, true> : stage2_kernel<1, false>);
     const bool reverse = stage2_reverse(ctx, M);
-    if (vec && reverse) kern = is_pinhole(cam->K) ? stage2_kernel<2, true, true> : stage2_kernel<2, false, true>;
+    if (vec && reverse) kern = is_pinhole(cam->K) ? stage2_kernel<2, true, SCAN_REVERSE> : stage2_kernel<2, false, SCAN_REVERSE>;
+    else if (vec && scan_nontemporal(ctx, M))
+        kern = is_pinhole(cam->K) ? stage2_kernel<2, true, SCAN_FORWARD_NONTEMPORAL> : stage2_kernel<2, false, SCAN_FORWARD_NONTEMPORAL>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), 0, ctx->stream, u, v, x, y, z, M, state, c, s1part, s1rows, part);
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
@@ -563,9 +568,13 @@ int sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const double
     const int grid2 = grid_for(vec ? (M + 1) / 2 : M, NT2, ctx->max_blocks2);
     auto k1 = vec ? (pin ? stage1_round_kernel<2, true, NT2> : stage1_round_kernel<2, false, NT2>)
                   : (pin ? stage1_round_kernel<1, true, NT2> : stage1_round_kernel<1, false, NT2>);
-    auto k2 = vec ? (reverse ? (pin ? stage2_round_kernel<2, true, true> : stage2_round_kernel<2, false, true>)
-                             : (pin ? stage2_round_kernel<2, true, false> : stage2_round_kernel<2, false, false>))
-                  : (pin ? stage2_round_kernel<1, true, false> : stage2_round_kernel<1, false, false>);
+    auto k2 = vec ? (reverse ? (pin ? stage2_round_kernel<2, true, SCAN_REVERSE> : stage2_round_kernel<2, false, SCAN_REVERSE>)
+                             : (pin ? stage2_round_kernel<2, true, SCAN_FORWARD> : stage2_round_kernel<2, false, SCAN_FORWARD>))
+                  : (pin ? stage2_round_kernel<1, true, SCAN_FORWARD> : stage2_round_kernel<1, false, SCAN_FORWARD>);
+    if (vec && !reverse && scan_nontemporal(ctx, M)) { // arrays far beyond the memory-side cache
+        k1 = pin ? stage1_round_kernel<2, true, NT2, SCAN_FORWARD_NONTEMPORAL> : stage1_round_kernel<2, false, NT2, SCAN_FORWARD_NONTEMPORAL>;
+        k2 = pin ? stage2_round_kernel<2, true, SCAN_FORWARD_NONTEMPORAL> : stage2_round_kernel<2, false, SCAN_FORWARD_NONTEMPORAL>;
+    }
     double* other = ctx->scratch + SCR_STATE2; // the state alternates between the caller's block and this one
     double* cur = state;
     hipStream_t st = ctx->stream;
@@ -642,6 +651,8 @@ int picp_profile_stage2(picp_ctx* ctx, const double* u, const double* v, const d
     ctx->rows2 = grid;
     auto kern = vec ? (is_pinhole(cam->K) ? stage2_kernel<2, true> : stage2_kernel<2, false>)
                     : (is_pinhole(cam->K) ? stage2_kernel<1, true> : stage2_kernel<1, false>);
+    if (vec && scan_nontemporal(ctx, M))
+        kern = is_pinhole(cam->K) ? stage2_kernel<2, true, SCAN_FORWARD_NONTEMPORAL> : stage2_kernel<2, false, SCAN_FORWARD_NONTEMPORAL>;
     hipEvent_t e0, e1;
     PICP_HIP_CHECK(hipEventCreate(&e0));
     PICP_HIP_CHECK(hipEventCreate(&e1));

@@ -701,7 +701,9 @@ __global__ __launch_bounds__(NTR) void icp_resident_kernel(const double* __restr
 constexpr int PERSISTENT_HOLD = PICP_HOLD;   // 100 KB of LDS ...
 constexpr int PERSISTENT_HOLDR = PICP_HOLDR; // ... + 40 KB and 30 registers per lane, beside 10 KB of static LDS
 static_assert((PERSISTENT_HOLD * 5 + PERSISTENT_HOLDR * 2) * NTR * sizeof(double) <= 146 * 1024, "LDS of the held correspondences");
-template <bool PINHOLE, bool REVERSE, bool SHARDED = false, int HOLD = 0, int HOLDR = 0>
+// ORDER: how the scans walk the arrays -- both forward; stage 2 backward (SCAN_REVERSE, for inputs the memory-side
+// cache can help with); both forward with non-temporal loads (SCAN_FORWARD_NONTEMPORAL, for inputs far beyond it).
+template <bool PINHOLE, int ORDER, bool SHARDED = false, int HOLD = 0, int HOLDR = 0>
 __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __restrict__ u, const double* __restrict__ v,
                                                             const double* __restrict__ x, const double* __restrict__ y,
                                                             const double* __restrict__ z, int64_t M,
@@ -728,8 +730,8 @@ __global__ __launch_bounds__(NTR) void icp_persistent_kernel(const double* __res
         u += M_held, v += M_held, x += M_held, y += M_held, z += M_held;
         M -= M_held;
     }
-    CorrStream<2, NTR, false> fwd;
-    CorrStream<2, NTR, REVERSE> rev; // stage 2's direction: see stage2_reverse()
+    CorrStream<2, NTR, ORDER == SCAN_REVERSE ? SCAN_FORWARD : ORDER> fwd;
+    CorrStream<2, NTR, ORDER> rev; // stage 2's direction: see stage2_reverse()
     fwd.start(u, v, x, y, z, M);
     if (HELD > 0) {
         const int64_t M_held = M_all - M;
@@ -1150,20 +1152,26 @@ int enqueue_persistent(picp_ctx* ctx, const double* u, const double* v, const do
     const bool hold = ctx->persistent_hold && M >= (int64_t)(PERSISTENT_HOLD + PERSISTENT_HOLDR + 2) * grid * NTR;
     using Kern = void (*)(const double*, const double*, const double*, const double*, const double*, int64_t, double*,
                           StartPose, CameraK, picp_schedule, GridExchange, double*, int, double*, PeerExchange);
-    static const Kern table[2][2][2][2] = {
-        {{{icp_persistent_kernel<false, false, false, 0, 0>, icp_persistent_kernel<true, false, false, 0, 0>},
-          {icp_persistent_kernel<false, true, false, 0, 0>, icp_persistent_kernel<true, true, false, 0, 0>}},
-         {{icp_persistent_kernel<false, false, true, 0, 0>, icp_persistent_kernel<true, false, true, 0, 0>},
-          {icp_persistent_kernel<false, true, true, 0, 0>, icp_persistent_kernel<true, true, true, 0, 0>}}},
-        {{{icp_persistent_kernel<false, false, false, PERSISTENT_HOLD, PERSISTENT_HOLDR>, icp_persistent_kernel<true, false, false, PERSISTENT_HOLD, PERSISTENT_HOLDR>},
-          {icp_persistent_kernel<false, true, false, PERSISTENT_HOLD, PERSISTENT_HOLDR>, icp_persistent_kernel<true, true, false, PERSISTENT_HOLD, PERSISTENT_HOLDR>}},
-         {{icp_persistent_kernel<false, false, true, PERSISTENT_HOLD, PERSISTENT_HOLDR>, icp_persistent_kernel<true, false, true, PERSISTENT_HOLD, PERSISTENT_HOLDR>},
-          {icp_persistent_kernel<false, true, true, PERSISTENT_HOLD, PERSISTENT_HOLDR>, icp_persistent_kernel<true, true, true, PERSISTENT_HOLD, PERSISTENT_HOLDR>}}}};
-    const Kern kern = table[hold ? 1 : 0][sharded ? 1 : 0][rev ? 1 : 0][pin ? 1 : 0];
+    const int order = rev ? SCAN_REVERSE : (scan_nontemporal(ctx, M) ? SCAN_FORWARD_NONTEMPORAL : SCAN_FORWARD);
+#define PICP_PK(PIN, ORD, SH, H, HR) icp_persistent_kernel<PIN, ORD, SH, H, HR>
+#define PICP_PK_ORDERS(SH, H, HR)                                                                       \
+    {                                                                                                   \
+        {PICP_PK(false, SCAN_FORWARD, SH, H, HR), PICP_PK(true, SCAN_FORWARD, SH, H, HR)},              \
+            {PICP_PK(false, SCAN_REVERSE, SH, H, HR), PICP_PK(true, SCAN_REVERSE, SH, H, HR)},          \
+        {                                                                                               \
+            PICP_PK(false, SCAN_FORWARD_NONTEMPORAL, SH, H, HR), PICP_PK(true, SCAN_FORWARD_NONTEMPORAL, SH, H, HR) \
+        }                                                                                               \
+    }
+    static const Kern table[2][2][3][2] = {
+        {PICP_PK_ORDERS(false, 0, 0), PICP_PK_ORDERS(true, 0, 0)},
+        {PICP_PK_ORDERS(false, PERSISTENT_HOLD, PERSISTENT_HOLDR), PICP_PK_ORDERS(true, PERSISTENT_HOLD, PERSISTENT_HOLDR)}};
+#undef PICP_PK_ORDERS
+#undef PICP_PK
+    const Kern kern = table[hold ? 1 : 0][sharded ? 1 : 0][order][pin ? 1 : 0];
     const unsigned held_bytes = hold ? (PERSISTENT_HOLD * 5 + PERSISTENT_HOLDR * 2) * NTR * sizeof(double) : 0;
     if (hold) { // above the default dynamic-LDS allowance: raise it once per kernel and device
-        static bool raised[8][MAX_DEVICES] = {};
-        const int which = (sharded ? 4 : 0) + (rev ? 2 : 0) + (pin ? 1 : 0);
+        static bool raised[12][MAX_DEVICES] = {};
+        const int which = (sharded ? 6 : 0) + order * 2 + (pin ? 1 : 0);
         if (ctx->device >= MAX_DEVICES || !raised[which][ctx->device]) {
             PICP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)held_bytes));
