@@ -660,6 +660,13 @@ def bench_loop(args):
                               "registers, the other arrays streamed twice per iteration)",
                     "bytes_per_launch": loop_bytes, "mean_launch_ms": run_mean_ms, "min_launch_ms": run_min_ms,
                     **streamed_block(ctx, n_local, run_mean_ms)}
+            size_name = {1 << 23: "2p23", 1 << 24: "2p24", 1 << 26: "2p26"}.get(M)
+            if size_name:
+                tr, traffic_source = committed_counters(f"r*_pmc_traffic_stream_{size_name}.json", "icp_persistent_kernel")
+                traffic = tr["hbm_bytes_per_launch"] if tr else None
+                roof["traffic_note"] = ("bytes the L2s fetched and wrote per launch, from the committed FETCH_SIZE / WRITE_SIZE "
+                                        "passes of this command (the memory-side cache sits behind the L2s, so its hits are in "
+                                        "this figure); not collected in this run")
         elif mode == "peer":
             mean_ms = sum(launch_ms) / max(len(launch_ms), 1)
             achieved = loop_bytes / (mean_ms * 1e-3) / 1e9
