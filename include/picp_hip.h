@@ -270,8 +270,9 @@ int picp_sharded_rounds(picp_ctx* ctx, const double* u, const double* v, const d
  * whole loop, a larger or empty one is streamed from memory twice per iteration (all but a part of it
  * that the kernel keeps on chip, as picp_run does at such sizes); the two forms run
  * the same exchanges, so the choice is each rank's own (picp_set_resident_limit(ctx, 0): always stream).
- * Every wait inside the kernel is bounded: if a peer's record does not arrive (a rank died or was
- * never launched) the launch gives up, the call returns PICP_ERR_RETRY and the exchange is unusable
+ * Every wait inside the kernel is bounded (about a second; a launch's first exchange waits sixteen times as
+ * long, because the ranks' hosts reach their launches at different times): if a peer's record does not
+ * arrive (a rank died or was never launched) the launch gives up, the call returns PICP_ERR_RETRY and the exchange is unusable
  * until it has been destroyed and set up again; callers then fall back to picp_sharded_rounds.
  * The status is this rank's own: a rank can give up at the last exchange after publishing its record
  * while a slower rank still completes.  Ranks must therefore agree on the outcome (a logical AND over

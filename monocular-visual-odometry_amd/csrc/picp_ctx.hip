@@ -80,7 +80,7 @@ int picp_create(picp_ctx** out, int device, void* stream) {
     ctx->resident_limit = INT64_MAX; // i.e. whatever fits (resident_capacity)
     ctx->resident_spin_limit = 1u << 18;
     ctx->persistent_limit = INT64_MAX;
-    ctx->peer_spin_limit = 1u << 20; // about a second: ranks reach their launches at different times
+    ctx->peer_spin_limit = 1u << 20; // about a second; sixteen times that for a launch's first exchange, since the ranks' hosts reach their launches at different times
     if (const char* ex = getenv("PICP_PEER_SPIN_LIMIT")) { int k = atoi(ex); if (k >= 0) ctx->peer_spin_limit = (unsigned)k; }
     if (const char* ep = getenv("PICP_PERSISTENT_LIMIT")) ctx->persistent_limit = atoll(ep);
     ctx->persistent_hold = 1;

@@ -544,6 +544,50 @@ __device__ __forceinline__ double recip_nr(double p) {
     return r;
 }
 
+// Index of entry (i, j) of a symmetric 6 x 6 matrix in its row-major upper triangle (00,01,..,05,11,..,55).
+__device__ __forceinline__ constexpr int tri6(int i, int j) {
+    return i <= j ? i * 6 - (i * (i - 1)) / 2 + (j - i) : j * 6 - (j * (j - 1)) / 2 + (i - j);
+}
+
+// Solves A x = rhs for a symmetric positive definite 6 x 6 matrix A (upper triangle, tri6 order) entirely in
+// the calling lane's registers: an LDL^T factorisation with the right-hand side carried along as a seventh
+// row of L, then the back substitution.  No pivoting (not needed for a positive definite matrix), pivots'
+// reciprocals by recip_nr.  About sixty dependent float64 operations, 700 cycles for a wave that runs
+// nothing else -- and nothing in it crosses lanes: the same elimination spread over the lanes of a wave
+// (one matrix entry per lane, pivot by v_readlane, row and column entries by ds_bpermute) took 950 cycles in
+// isolation and 1 600 inside the loop kernels, where the LDS crossbar is shared with the other waves
+// (tools/gj_probe.hip).
+__device__ __forceinline__ void solve_spd6(const double (&A)[21], const double (&rhs)[6], double (&x)[6]) {
+    double L[7][6]; // L[i][j], i > j: the unit lower factor; row 6: the right-hand side's forward substitution
+    double d[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double v[6];
+        double dj = A[tri6(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            v[k] = L[j][k] * d[k];
+            dj = __builtin_fma(-L[j][k], v[k], dj);
+        }
+        d[j] = dj;
+        const double inv = recip_nr(dj);
+#pragma unroll
+        for (int i = j + 1; i < 7; ++i) {
+            double t = (i < 6) ? A[tri6(i, j)] : rhs[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t = __builtin_fma(-L[i][k], v[k], t);
+            L[i][j] = t * inv;
+        }
+    }
+#pragma unroll
+    for (int j = 5; j >= 0; --j) { // L^T x = z with z_j = y_j / d_j = L[6][j]
+        double t = L[6][j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) t = __builtin_fma(-L[i][j], x[i], t);
+        x[j] = t;
+    }
+}
+
 // Inverse of a pose matrix [A t; 0 0 0 1] as [A^-1, -A^-1 t; 0 0 0 1] with A^-1 = adj(A) / det(A).
 // The reference calls np.linalg.inv (src/ProjectiveICP.py:232), a general LU inverse; a
 // rigid-transform shortcut [A^T | -A^T t] is not usable, because A is built from float32 sines and
@@ -752,6 +796,7 @@ struct StepShared {
     int ring_slot; // slot of the slope ring buffer that receives `slope`, or -1
     int improved;  // this iteration's error is the smallest so far (first minimum wins, :249)
     double next[4]; // solve_step_lanes: what the next iteration's stages read besides Tinv (NEXT_*)
+    double sys[PICP_S2_DOUBLES]; // solve_step_lanes: the stage-2 record, for the pose wave's uniform reads
 #ifdef PICP_STAMPS
     unsigned long long t[6]; // diagnostic build: clock stamps inside solve_step
 #endif
@@ -782,17 +827,27 @@ struct LaneRecord {
 };
 
 // Pose chain, one whole wave (all 64 lanes active): H and b of the chosen set, damped solve, v2T, pose
-// product, inverse (src/ProjectiveICP.py:269-271, :232).  On a single lane this is a chain of some
-// three hundred dependent float64 operations, six of them divisions or square roots, and every
-// iteration of the loop waits for it; spread over the lanes it is six elimination steps:
-//   lane 8 i + k holds entry (i, k) of the augmented matrix [H + lambda I | -b] (6 x 7); Gauss-Jordan
-//   step j divides row j by the pivot and subtracts its multiples from every other row, every entry
-//   in its own lane, with the pivot broadcast by v_readlane and the entries (i, j) and (j, k) fetched
-//   by ds_bpermute.  The matrix is symmetric positive definite (lambda >= min damping > 0), for which
-//   elimination without pivoting is stable; the reference's np.linalg.lstsq returns the same unique
-//   solution.  After step 5 column 6 holds dx.
-// The three float32 sine/cosine pairs of v2T are computed by three lanes at once; the rest (pose
-// product, cofactor inverse) has uniform operands and is computed by every lane alike, lane 0 stores it.
+// product, inverse (src/ProjectiveICP.py:269-271, :232).  Every iteration of the loop waits for it.
+// The 6 x 6 system [H + lambda I] dx = -b is solved by every lane for itself (solve_spd6: the operands are the
+// same in all lanes, so nothing has to cross lanes; the matrix is symmetric positive definite -- lambda >= min
+// damping > 0 --, for which elimination without pivoting is stable, and the reference's np.linalg.lstsq returns
+// the same unique solution).  The three float32 sine/cosine pairs of v2T are computed by three lanes at once;
+// the rest (pose product, cofactor inverse) has uniform operands and is computed by every lane alike, lane 0
+// stores it.
+template <class R2, int I = 0>
+__device__ __forceinline__ void fetch_system(const R2& r2, bool have, double lambda, double (&A)[21], double (&rhs)[6]) {
+    if constexpr (I < 21) {
+        A[I] = have ? r2.template at<S2_H + I>() : 0.0;
+        fetch_system<R2, I + 1>(r2, have, lambda, A, rhs);
+    } else if constexpr (I < 27) {
+        rhs[I - 21] = have ? -r2.template at<S2_B + (I - 21)>() : -0.0; // :270
+        fetch_system<R2, I + 1>(r2, have, lambda, A, rhs);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) A[tri6(j, j)] += lambda; // :269
+    }
+}
+
 template <class R2>
 __device__ __forceinline__ void step_pose_wave(const double* st, const StageScalars& q, const R2& r2, StepShared* sh) {
     const int lane = threadIdx.x & 63;
@@ -804,41 +859,23 @@ __device__ __forceinline__ void step_pose_wave(const double* st, const StageScal
         for (int i = 0; i < 16; ++i) T1[i] = st[ST_W_T_C + i];
     } else {
         const bool have = (q.n1 != 0.0); // else H = 0, b = 0 (:300)
-        const int i = lane >> 3, k = lane & 7;
-        const bool in_h = (i < 6 && k < 6), in_b = (i < 6 && k == 6);
-        const int lo = i < k ? i : k, hi = i < k ? k : i;
-        const int tri = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo); // index of (lo, hi) in the row-major upper triangle
-        const double entry = r2.dyn(in_h ? S2_H + tri : (in_b ? S2_B + i : 0)); // fetched by every lane of the wave
-        double a = 0.0;
-        if (in_h) {
-            a = have ? entry : 0.0;
-            if (i == k) a += st[ST_LAMBDA]; // :269
-        } else if (in_b) {
-            a = have ? -entry : -0.0; // :270
+        // the system (H + lambda I) dx = -b (:269-270), the same in every lane: entry t of the record by
+        // v_readlane (or a uniform load), then the per-lane solve
+        const double lambda = st[ST_LAMBDA];
+        double A[21], rhs[6];
+        fetch_system(r2, have, lambda, A, rhs);
+#ifdef PICP_STAMPS
+        {
+            double keep = A[0] + A[20] + rhs[5]; // the stamp below follows the fetches
+            asm volatile("" : "+v"(keep));
+            if (lane == 0) sh->t[3] = __builtin_amdgcn_s_memrealtime();
+            A[0] += keep * 0.0;
         }
-#define PICP_GJ_STEP(J)                                                      \
-    {                                                                        \
-        const double r = recip_nr(lane_bcast<(J) * 8 + (J)>(a));             \
-        const double aij = lane_gather(a, i * 8 + (J));                      \
-        const double ajk = lane_gather(a, (J) * 8 + k);                      \
-        a = (i == (J)) ? a * r : __builtin_fma(-(aij * r), ajk, a);          \
-    }
-        PICP_GJ_STEP(0)
-        PICP_GJ_STEP(1)
-        PICP_GJ_STEP(2)
-        PICP_GJ_STEP(3)
-        PICP_GJ_STEP(4)
-        PICP_GJ_STEP(5)
-#undef PICP_GJ_STEP
+#endif
+        solve_spd6(A, rhs, dx);
 #ifdef PICP_STAMPS
         if (lane == 0) sh->t[4] = __builtin_amdgcn_s_memrealtime();
 #endif
-        dx[0] = lane_bcast<0 * 8 + 6>(a);
-        dx[1] = lane_bcast<1 * 8 + 6>(a);
-        dx[2] = lane_bcast<2 * 8 + 6>(a);
-        dx[3] = lane_bcast<3 * 8 + 6>(a);
-        dx[4] = lane_bcast<4 * 8 + 6>(a);
-        dx[5] = lane_bcast<5 * 8 + 6>(a);
         // v2T (src/geometry_utils.py:38-45): lanes 0, 1, 2 take the three angles
         const double ang = (lane == 0) ? dx[3] : ((lane == 1) ? dx[4] : dx[5]);
         float fs, fc;
@@ -1085,10 +1122,25 @@ __device__ __forceinline__ bool solve_step_lanes(double* st, double g1, double g
         __syncthreads();
         return false;
     }
-    if (tid < 64) step_pose_wave(st, q, r2, sh);
+#ifdef PICP_STAMPS
+    if (tid == 0) sh->t[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (tid < 64) {
+        // Every lane of the pose wave needs all 27 entries of the record.  Lane-to-scalar reads (v_readlane, two
+        // per entry) took 0.4 us here; one store per lane and uniform 16-byte loads (LDS broadcasts them) take a
+        // quarter of that.  Same wave, so the loads follow the store without a barrier.
+        if (tid < PICP_S2_DOUBLES) sh->sys[tid] = g2;
+        step_pose_wave(st, q, MemRecord{sh->sys}, sh);
+    }
+#ifdef PICP_STAMPS
+    if (tid == 0) sh->t[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     StepShared mine; // the schedule chain's results, in the registers of the lane that computed them
     if (tid == 64) {
         step_schedule_chain(st, q, sc, sh, mine);
+#ifdef PICP_STAMPS
+        sh->t[2] = __builtin_amdgcn_s_memrealtime();
+#endif
         sh->next[NEXT_THR] = mine.thr;
         sh->next[NEXT_MODE] = 0.0;
         sh->next[NEXT_IT] = (double)mine.it;
@@ -1096,6 +1148,12 @@ __device__ __forceinline__ bool solve_step_lanes(double* st, double g1, double g
     }
     if (hist_row != nullptr && tid >= 128 && tid < 192) fill_history_linear(hist_row, q, r2, tid - 128);
     __syncthreads();
+#ifdef PICP_STAMPS
+    if (tid == 0 && blockIdx.x == 0 && sh->it == 6 && PICP_STAMPS > 1)
+        printf("solve_step_lanes: system fetched at %.2f, solved at %.2f, pose product at %.2f, pose wave %.2f us, schedule chain done at %.2f, barrier passed at %.2f\n",
+               (sh->t[3] - sh->t[0]) * 0.01, (sh->t[4] - sh->t[0]) * 0.01, (sh->t[5] - sh->t[0]) * 0.01, (sh->t[1] - sh->t[0]) * 0.01, (sh->t[2] - sh->t[0]) * 0.01,
+               (__builtin_amdgcn_s_memrealtime() - sh->t[0]) * 0.01);
+#endif
     // state update (:231-238) and history row, one entry per lane; nobody waits for it here
     if (tid < 16) {
         const double t = sh->T1[tid];

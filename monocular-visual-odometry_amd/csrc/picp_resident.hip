@@ -317,6 +317,9 @@ struct PeerExchange {
     int rank, world;     // world == 1: no exchange
     unsigned epoch0;     // exchanges completed by earlier launches
     unsigned spin_limit; // re-reads before a waiting thread gives up
+    unsigned first_spin_limit; // the same for a launch's first exchange: the ranks' hosts reach their launches at
+                               // different times (input set-up, a stalled process), so the first record of a peer
+                               // may be seconds away; later ones follow within an iteration's time
 };
 
 template <int NV>
@@ -353,7 +356,7 @@ __device__ __forceinline__ bool cross_total(double mine, double& out, const Peer
         for (;;) {
             v = __hip_atomic_load(cur + (size_t)r * RW + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (!is_sentinel(v)) break;
-            if (++spins > px.spin_limit) {
+            if (++spins > (e == px.epoch0 ? px.first_spin_limit : px.spin_limit)) {
                 *lds_flag = 1;
                 break;
             }
@@ -1033,6 +1036,7 @@ static PeerExchange peer_exchange_of(const picp_ctx* ctx, bool sharded) {
         px.world = ctx->peer_world;
         px.epoch0 = ctx->peer_epoch;
         px.spin_limit = ctx->peer_spin_limit;
+        px.first_spin_limit = ctx->peer_spin_limit > (0xffffffffu >> 4) ? 0xffffffffu : ctx->peer_spin_limit << 4;
     }
     return px;
 }

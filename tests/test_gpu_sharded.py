@@ -187,7 +187,9 @@ def _peer_rank(rank, world, port, out):
             q = _peer_params(n_it, over)
             sched = p._lib.schedule_struct(n_it, q["min_inliers"], q["kernel_threshold"], q["min_kernel_threshold"],
                                            q["max_kernel_threshold"], q["damping"], q["min_damping"], q["max_damping"])
-            res, hist = ctx.run_sharded(ctx.soa(uv[lo:hi], pw[lo:hi]), po.v2T(v0), cam, sched)
+            corr = ctx.soa(uv[lo:hi], pw[lo:hi])
+            dist.barrier()                                       # the inputs of all ranks are ready: launch together
+            res, hist = ctx.run_sharded(corr, po.v2T(v0), cam, sched)
             results.append((np.array(list(res.T)).reshape(4, 4), int(res.valid), int(res.num_iterations),
                             int(res.best_index), hist.copy()))
     dist.barrier()
