@@ -457,6 +457,8 @@ __device__ __forceinline__ void stage2_kept(const double* __restrict__ T, const 
     s.n += keep ? 1u : 0u;
 }
 
+#ifndef PICP_STAGE_PROBE // tools/stage_probe.hip includes this file up to here: the stages' per-correspondence code alone
+
 // MODERATE: the lean form of stage 2 (stage2_kept).  It needs every loaded value, the camera matrix
 // (checked by the host) and every pose of the loop to be moderate(): the lanes count what is not, the
 // count travels with the first exchange of every iteration, and when it is not zero every workgroup
@@ -1245,5 +1247,7 @@ int enqueue_batched_resident(picp_ctx* ctx, int B, int64_t max_count, const doub
     PICP_HIP_CHECK(hipGetLastError());
     return PICP_OK;
 }
+
+#endif // PICP_STAGE_PROBE
 
 } // namespace picp
