@@ -316,12 +316,15 @@ def _agree(ok, group=None):
 
 
 def state_checksum(state):
-    """62-bit checksum of the bit patterns of a loop state block (device tensor of 96 doubles): a one-ulp
-    difference in any entry changes it."""
+    """62-bit checksum of the bit patterns of a loop state block (device tensor of 96 doubles): a difference in
+    any single bit of any entry changes it -- the last bit of a mantissa as well as a sign (the weighted sum is
+    formed modulo 2^64 with odd weights, so no single bit is lost, and its top half is folded onto the bottom half
+    before the two top bits, where a sign or top exponent bit lands, are cut off)."""
     import torch
     bits = state.view(torch.int64)
     weights = torch.arange(1, 2 * bits.numel(), 2, dtype=torch.int64, device=bits.device)
-    return int((bits * weights).sum().item()) & ((1 << 62) - 1)
+    total = int((bits * weights).sum().item()) & ((1 << 64) - 1)
+    return (total ^ (total >> 32)) & ((1 << 62) - 1)
 
 
 def replicas_identical(state, group=None):
