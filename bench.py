@@ -314,36 +314,48 @@ def choose_exchange(pkg, ctx, dist, world, backend, step_peer, step_stages, stag
         return True, ""
 
     notes = []
-    if want in ("auto", "peer") and S.init_peer_exchange(ctx):
+    # The exchange memory is uncached device memory where the runtime grants it; should the set-up or the trial fail
+    # with it, the whole attempt is repeated once with fine-grained memory (the same decision on every rank: it
+    # depends on agreed outcomes and on the environment the launcher gave all ranks).
+    kinds = [] if want not in ("auto", "peer") else ([None, "finegrained"] if "PICP_PEER_MEMORY" not in os.environ else [None])
+    for kind in kinds:
+        again = " (second attempt, fine-grained exchange memory)" if kind else ""
+        if kind:
+            os.environ["PICP_PEER_MEMORY"] = kind
+        if not S.init_peer_exchange(ctx):
+            notes.append(f"the in-kernel exchange could not be set up{again} (see stderr for the pair of GPUs)")
+            continue
         ok, why = trial(step_peer, lambda: ctx._run_state, "in-kernel exchange")
-        if ok:
-            # both paths work: keep the in-kernel exchange unless the stage launches are faster on this
-            # machine (they are not where it was rehearsed; between real GPUs the peer stores are untried)
-            text = (f"in-kernel exchange through peer memory (HIP IPC, xGMI stores into {S.peer_memory_kind(ctx)}), one "
-                    f"launch per loop; {TRIAL_LOOPS} trial loops equal to the stage launches' result and bit-identical "
-                    "between the ranks")
-            if want == "peer":
-                return "peer", text, None
-            try:
-                ms_peer, failed = loop_ms(step_peer), False
-            except pkg._lib.PicpError as e:
-                print(f"rank {rank}: in-kernel exchange failed while being timed: {e}", file=sys.stderr)
-                ms_peer, failed = float("inf"), True
-                max_over_ranks(0.0, world, backend)                  # the collective of loop_ms a rank without the failure is in
-            failed = not S._agree(not failed)
-            ms_stages = loop_ms(lambda: step_stages("torch"))
-            if not failed and ms_peer <= ms_stages:
-                return "peer", (f"{text} ({ms_peer:.3f} ms per loop in the trial; stage launches with {backend} "
-                                f"all-reduces {ms_stages:.3f} ms)"), ms_peer
-            why = ("it failed while being timed" if failed else
-                   f"the stage launches were faster in the trial ({ms_stages:.3f} ms per loop against {ms_peer:.3f} ms)")
-            notes.append(f"the in-kernel exchange passed its trial but {why}")
-            print(f"rank {rank}: in-kernel exchange not used: {why}", file=sys.stderr)
-        else:
-            notes.append(f"the in-kernel exchange was set up but failed its trial ({why})")
+        if not ok:
+            notes.append(f"the in-kernel exchange was set up but failed its trial{again} ({why})")
+            S.shutdown_peer_exchange(ctx)
+            continue
+        # both paths work: keep the in-kernel exchange unless the stage launches are faster on this
+        # machine (they are not where it was rehearsed; between real GPUs the peer stores are untried)
+        text = (f"in-kernel exchange through peer memory (HIP IPC, xGMI stores into {S.peer_memory_kind(ctx)}), one "
+                f"launch per loop; {TRIAL_LOOPS} trial loops equal to the stage launches' result and bit-identical "
+                "between the ranks")
+        if notes:
+            text += "; before that: " + "; ".join(notes)
+        if want == "peer":
+            return "peer", text, None
+        try:
+            ms_peer, failed = loop_ms(step_peer), False
+        except pkg._lib.PicpError as e:
+            print(f"rank {rank}: in-kernel exchange failed while being timed: {e}", file=sys.stderr)
+            ms_peer, failed = float("inf"), True
+            max_over_ranks(0.0, world, backend)                  # the collective of loop_ms a rank without the failure is in
+        failed = not S._agree(not failed)
+        ms_stages = loop_ms(lambda: step_stages("torch"))
+        if not failed and ms_peer <= ms_stages:
+            return "peer", (f"{text} ({ms_peer:.3f} ms per loop in the trial; stage launches with {backend} "
+                            f"all-reduces {ms_stages:.3f} ms)"), ms_peer
+        why = ("it failed while being timed" if failed else
+               f"the stage launches were faster in the trial ({ms_stages:.3f} ms per loop against {ms_peer:.3f} ms)")
+        notes.append(f"the in-kernel exchange passed its trial but {why}")
+        print(f"rank {rank}: in-kernel exchange not used: {why}", file=sys.stderr)
         S.shutdown_peer_exchange(ctx)
-    elif want in ("auto", "peer"):
-        notes.append("the in-kernel exchange could not be set up (see stderr for the pair of GPUs)")
+        break
     # (on gloo only for rehearsals of the set-up's failure paths: RCCL refuses two ranks on one device)
     native_allowed = backend == "nccl" or want == "rccl" or os.environ.get("PICP_BENCH_NATIVE_ON_GLOO") == "1"
     if want in ("auto", "rccl") and native_allowed and S.init_native_exchange(ctx):

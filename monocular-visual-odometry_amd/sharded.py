@@ -222,6 +222,9 @@ def init_peer_exchange(ctx, group=None):
     ok = world <= _lib.PEER_MAX_RANKS
     buf = C.create_string_buffer(_lib.PEER_HANDLE_BYTES)
     ok = ok and not _injected("peer_create") and lib.picp_peer_create(ctx.handle, rank, world, buf) == _lib.PICP_OK
+    if ok and _injected("peer_uncached") and peer_memory_kind(ctx).startswith("uncached"):
+        ok = False                                 # rehearsal: as if uncached memory could not be shared between processes
+        print(f"rank {rank}: injected failure (PICP_INJECT_FAILURE=peer_uncached): uncached exchange memory refused", file=sys.stderr)
     bus = C.create_string_buffer(_lib.BUS_ID_BYTES)
     bus_id = bus.value if lib.picp_device_bus_id(ctx.handle, bus, _lib.BUS_ID_BYTES) == _lib.PICP_OK else b""
     mine = (bytes(buf.raw) if ok else None, bus_id, socket.gethostname())

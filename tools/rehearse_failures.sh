@@ -25,6 +25,7 @@ run none PICP_INJECT_FAILURE= || exit 1
 run peer_access PICP_INJECT_FAILURE=peer_access || exit 1
 run peer_create PICP_INJECT_FAILURE=peer_create || exit 1
 run trial_bits PICP_INJECT_FAILURE=trial_bits || exit 1
+run peer_uncached PICP_INJECT_FAILURE=peer_uncached || exit 1   # second attempt with fine-grained memory succeeds
 run fail_step PICP_BENCH_FAIL_STEP=30 || exit 1
 run comm_ready PICP_INJECT_FAILURE=peer_access,comm_ready PICP_BENCH_EXCHANGE=auto PICP_BENCH_NATIVE_ON_GLOO=1 || exit 1
 run finegrained PICP_PEER_MEMORY=finegrained || exit 1
