@@ -45,7 +45,8 @@ constexpr int NTR = 512;                 // eight waves: two per SIMD
 constexpr int RW = PICP_S2_DOUBLES;      // doubles per exchange record (both stages use one slot layout)
 constexpr int R_MAX = 16;                // correspondences per thread
 constexpr int R_KEEP_MAX = 8;            // up to here LDS also keeps stage 1's chi and 1/z for stage 2
-constexpr int R_LEAN_MAX = 6;            // up to here the lean form of stage 2 pays (at 8 it spills: 12.7 against 12.45 us per iteration)
+constexpr int R_LEAN_MAX = 6;            // up to here the lean form of stage 2 pays with a general camera matrix (at 8 it spills)
+constexpr int R_LEAN_MAX_PINHOLE = 8;    // ... and with a pinhole matrix (256 registers at 8, none spilled: 222.9 against 226.3 us per launch at 2^20 x 20)
 constexpr int SLOTS = 3;
 constexpr int FIRST_LOOK_DELAY = 16;      // s_sleep units (64 clocks) between publishing and the first poll
 constexpr int FIRST_LOOK_DELAY_WIDE = 12; // the same for the 32-double records (swept 0 .. 20 for both: flat within 0.1 us from 12 to 16, 0.3 - 0.7 us worse at 0 .. 8)
@@ -1058,11 +1059,14 @@ static void launch_resident(picp_ctx* ctx, int grid, const double* u, const doub
     const PeerExchange px = peer_exchange_of(ctx, sharded);
     // The lean form where it pays (up to R_LEAN_MAX correspondences per thread), unless a recent loop met
     // immoderate values or the camera matrix itself is not moderate.  Sharded: the general form only.
-    bool lean = (R <= R_LEAN_MAX) && ctx->full_select_calls == 0 && !sharded;
+    const bool pinhole = is_pinhole(cam->K);
+    constexpr bool LEAN_P = (R <= R_LEAN_MAX_PINHOLE), LEAN_G = (R <= R_LEAN_MAX);
+    const bool can_lean = pinhole ? LEAN_P : LEAN_G;
+    bool lean = can_lean && ctx->full_select_calls == 0 && !sharded;
     for (int i = 0; i < 9; ++i) lean = lean && fabs(cam->K[i]) < 0x1p199; // moderate(), as the kernel tests its values
-    if ((R <= R_LEAN_MAX) && ctx->full_select_calls > 0 && !sharded) ctx->full_select_calls -= 1;
-    auto kern = is_pinhole(cam->K) ? (lean ? icp_resident_kernel<R, true, (R <= R_LEAN_MAX)> : icp_resident_kernel<R, true, false>)
-                                   : (lean ? icp_resident_kernel<R, false, (R <= R_LEAN_MAX)> : icp_resident_kernel<R, false, false>);
+    if (can_lean && ctx->full_select_calls > 0 && !sharded) ctx->full_select_calls -= 1;
+    auto kern = pinhole ? (lean ? icp_resident_kernel<R, true, LEAN_P> : icp_resident_kernel<R, true, false>)
+                        : (lean ? icp_resident_kernel<R, false, LEAN_G> : icp_resident_kernel<R, false, false>);
     if constexpr (R == 2 || R == 8 || R == 16) { // the sizes a sharded run is rounded up to (enqueue_resident)
         if (sharded) kern = is_pinhole(cam->K) ? icp_resident_kernel<R, true, false, true> : icp_resident_kernel<R, false, false, true>;
     }
