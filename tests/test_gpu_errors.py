@@ -177,3 +177,49 @@ def test_batched_and_linearize_reject_unusable_arguments(env):
     assert lib.picp_run_batched(*bad) == INVALID and "null argument" in message(ctx)
     bad = list(args); bad[11] = 0
     assert lib.picp_run_batched(*bad) == INVALID and "null argument" in message(ctx)
+
+
+def test_projection_gather_and_exchange_calls_reject_misuse(env):
+    ctx, cam, _, corr = env
+    lib = ctx.lib
+    N = 100
+    inside = torch.zeros(N, dtype=torch.int32, device=corr[0].device)
+    uu, vv = ctx.empty(N), ctx.empty(N)
+    c_T_w = np.ascontiguousarray(np.linalg.inv(true_pose()).reshape(16))
+    good = [ctx.handle, corr[2].data_ptr(), corr[3].data_ptr(), corr[4].data_ptr(), N, c_T_w.ctypes.data, C.byref(cam),
+            inside.data_ptr(), uu.data_ptr(), vv.data_ptr()]
+    assert lib.picp_project(*good) == L.PICP_OK
+    bad = list(good); bad[4] = -1
+    assert lib.picp_project(*bad) == INVALID and "negative" in message(ctx)
+    bad = list(good); bad[7] = 0
+    assert lib.picp_project(*bad) == INVALID and "null array" in message(ctx)
+    broken = c_T_w.copy(); broken[13] = 0.5
+    bad = list(good); bad[5] = broken.ctypes.data
+    assert lib.picp_project(*bad) == INVALID
+
+    idx = torch.arange(N, dtype=torch.int64, device=corr[0].device)
+    pos1 = ctx.to_device(np.zeros((N, 2)))
+    pos2 = ctx.to_device(np.zeros((N, 3)))
+    out = [ctx.empty(N) for _ in range(5)]
+    good = [ctx.handle, idx.data_ptr(), idx.data_ptr(), N, pos1.data_ptr(), pos2.data_ptr(), *[o.data_ptr() for o in out]]
+    assert lib.picp_gather_pairs(*good) == L.PICP_OK
+    bad = list(good); bad[3] = -4
+    assert lib.picp_gather_pairs(*bad) == INVALID and "negative" in message(ctx)
+    bad = list(good); bad[5] = 0
+    assert lib.picp_gather_pairs(*bad) == INVALID and "null array" in message(ctx)
+
+    # the exchanges between GPUs, used out of order
+    handles = C.create_string_buffer(L.PEER_HANDLE_BYTES * 2)
+    assert lib.picp_peer_connect(ctx.handle, handles) == INVALID and "picp_peer_create first" in message(ctx)
+    one = C.create_string_buffer(L.PEER_HANDLE_BYTES)
+    assert lib.picp_peer_create(ctx.handle, 3, 2, one) == INVALID and "rank 3 of 2" in message(ctx)
+    assert lib.picp_peer_create(ctx.handle, 0, L.PEER_MAX_RANKS + 1, one) == INVALID
+    assert lib.picp_peer_world(ctx.handle) == 0
+    buf = ctx.zeros(4)
+    assert lib.picp_comm_allreduce(ctx.handle, buf.data_ptr(), 4) == INVALID and "no communicator" in message(ctx)
+    assert lib.picp_comm_init(ctx.handle, None, 0, 1) == INVALID
+    small = C.create_string_buffer(8)
+    assert lib.picp_comm_unique_id(small, 8) == INVALID and "bytes" in message(ctx)
+    bus = C.create_string_buffer(4)
+    assert lib.picp_device_bus_id(ctx.handle, bus, 4) == INVALID
+    assert lib.picp_peer_destroy(ctx.handle) == L.PICP_OK            # nothing to destroy is not an error
